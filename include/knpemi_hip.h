@@ -1,0 +1,208 @@
+/*
+ * knpemi_hip.h -- C ABI of libknpemi_hip.so: the MI355X-native (gfx950) replacement for the
+ * third-party native code that the reference (hherlyng/knp-emi-cgx) calls on its per-timestep
+ * KNP-EMI assemble-and-solve path.  Plain pointers and sizes only; no torch / DOLFINx / PETSc types.
+ *
+ * What each entry point replaces (file:line relative to the reference repository):
+ *
+ *   knp_create / knp_get_layout / knp_get_csr_pattern
+ *        multiphenicsx.fem.DofMapRestriction + create_matrix_block / create_vector_block
+ *        (src/CGx/KNPEMI/KNPEMIx_problem.py:75-94, src/CGx/KNPEMI/KNPEMIx_solver.py:157-161)
+ *   knp_set_params                   constants of the forms (KNPEMIx_problem.py:459-462, 909-981)
+ *   knp_set_program / knp_set_program_constants
+ *        the FFCx-JIT-compiled membrane integrands built from IonicModel._eval
+ *        (KNPEMIx_problem.py:504-555, 609-610, 641-642; KNPEMIx_ionic_model.py:_eval methods)
+ *   knp_assemble_matrix              assemble_matrix_block(A, a)      (KNPEMIx_solver.py:110-115)
+ *   knp_assemble_rhs                 assemble_vector_block(b, L, a)   (KNPEMIx_solver.py:116)
+ *   knp_assemble_precond             assemble_matrix_block(P)         (KNPEMIx_solver.py:118-127,
+ *                                    form KNPEMIx_problem.py:657-744)
+ *   knp_set_nullspace / knp_project_nullspace
+ *        MatNullSpace create/test/remove                              (KNPEMIx_solver.py:297-335)
+ *   knp_pc_setup / knp_amg_*         PC setup: ksp.setUp() with pc_type hypre (KNPEMIx_solver.py:211-214,
+ *                                    269-273, 386-389) -> vertex-block Jacobi / aggregation AMG
+ *   knp_gmres_solve                  ksp.solve(b, x): GMRES(30), left PC, CGS, preconditioned norm
+ *                                    (KNPEMIx_solver.py:435; options :276-280)
+ *   knp_pack / knp_unpack            BlockVecSubVectorWrapper copies + phi_m = phi_i - phi_e
+ *                                    (KNPEMIx_solver.py:177-209, 452-468)
+ *   knp_hh_update                    HodgkinHuxley.update_gating_variables
+ *                                    (KNPEMIx_ionic_model.py:605-671)
+ *   knp_l2_norms                     assemble_scalar(inner(phi,phi)*dx(tag)) (src/CGx/KNPEMI/main.py:70-84)
+ *   knp_set_comm                     the MPI calls hidden in PETSc/DOLFINx (ghost updates
+ *                                    KNPEMIx_solver.py:439,459,468; Allreduce inside KSPSolve)
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative KNP_E_* otherwise; knp_last_error() gives text.
+ *     Nothing throws or exits across the ABI.  Non-convergence is a *reason code*, not an error.
+ *   - a ctx is bound to the HIP device current at knp_create and to one stream (knp_set_stream);
+ *     it is not thread-safe; one ctx per GPU.
+ *   - "host" pointers are read/written by the CPU during the call; "device" pointers are HBM
+ *     addresses owned by the caller (e.g. torch tensors) unless stated otherwise.
+ *   - unknown numbering: node = (vertex, side); DoF = 4*node + f, f = 0..2 ions, f = 3 potential.
+ *     Nodes follow vertex order; a membrane vertex contributes its intra node then its extra node.
+ *     Owned vertices come first (multi-GPU): rows exist for owned nodes only, columns may refer
+ *     to ghost nodes; vectors have n_dof_local entries (owned part first).
+ */
+#ifndef KNPEMI_HIP_H
+#define KNPEMI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KNP_MAX_IONS 3
+#define KNP_MAX_AUX 8
+#define KNP_MAX_PROG_REGS 48
+#define KNP_MAX_AMG_LEVELS 16
+
+#define KNP_OK 0
+#define KNP_E_ARG (-1)
+#define KNP_E_HIP (-2)
+#define KNP_E_STATE (-3)
+#define KNP_E_ALLOC (-4)
+#define KNP_E_MESH (-5)
+
+/* converged reasons (mirroring PETSc's KSPConvergedReason values) */
+#define KNP_CONVERGED_RTOL 2
+#define KNP_CONVERGED_ATOL 3
+#define KNP_DIVERGED_ITS (-3)
+#define KNP_DIVERGED_DTOL (-4)
+#define KNP_DIVERGED_NANORINF (-9)
+
+/* preconditioner kinds */
+#define KNP_PC_NONE 0
+#define KNP_PC_VBJACOBI 1 /* per-vertex 4x4 / 8x8 blocks of A, refreshed with A */
+#define KNP_PC_AMG 2      /* multilevel V-cycle on P (levels supplied with knp_amg_*) */
+
+/* membrane-program opcodes: instruction = {op, dst, a, b}, registers are doubles */
+enum {
+    KNP_OP_CONST = 0, /* dst = consts[a] */
+    KNP_OP_KI = 1,    /* dst = k_i^a at the quadrature point */
+    KNP_OP_KE = 2,    /* dst = k_e^a */
+    KNP_OP_PHIM = 3,  /* dst = phi_m */
+    KNP_OP_AUX = 4,   /* dst = aux field a (gating variables, ...) */
+    KNP_OP_X = 5,     /* dst = coordinate a */
+    KNP_OP_ADD = 6, KNP_OP_SUB = 7, KNP_OP_MUL = 8, KNP_OP_DIV = 9, KNP_OP_NEG = 10,
+    KNP_OP_POW = 11, KNP_OP_LN = 12, KNP_OP_EXP = 13, KNP_OP_SQRT = 14,
+    KNP_OP_MAX = 15, KNP_OP_MIN = 16, KNP_OP_ABS = 17,
+    KNP_OP_LT = 18, KNP_OP_GT = 19, KNP_OP_LE = 20, KNP_OP_GE = 21, KNP_OP_EQ = 22,
+    KNP_OP_AND = 23, KNP_OP_OR = 24, KNP_OP_NOT = 25,
+    KNP_OP_SEL = 26,   /* dst = (reg[a] != 0) ? reg[b] : reg[dst]   (dst preloaded with the else-value) */
+    KNP_OP_OUT = 27,   /* I_ch^a += reg[b] */
+    KNP_OP_MOV = 28,
+    KNP_OP_POWI = 29   /* dst = reg[a]^b with integer literal b */
+};
+
+typedef struct knp_ctx knp_ctx;
+
+typedef struct {
+    int32_t dim;              /* 2 (triangles) or 3 (tetrahedra) */
+    int32_t n_vertices;       /* local vertices, owned first */
+    int32_t n_vertices_owned; /* == n_vertices on one GPU */
+    int32_t n_cells;
+    int32_t n_cells_owned;    /* owned cells come first; used by knp_l2_norms only */
+    const int32_t* cells;     /* host [n_cells*(dim+1)] local vertex ids */
+    const double* coords;     /* host [n_vertices*dim], metres */
+    const uint8_t* cell_side; /* host [n_cells] 0 = intracellular, 1 = extracellular */
+    int32_t n_gamma;
+    const int32_t* gamma;     /* host [n_gamma*4] (cell+, lf+, cell-, lf-), '+' = intracellular */
+    const int32_t* gamma_prog;/* host [n_gamma] membrane-program id of the facet */
+    int32_t n_q;              /* facet quadrature */
+    const double* q_pts;      /* host [n_q*dim] barycentric coordinates on the facet */
+    const double* q_w;        /* host [n_q] weights, sum 1 */
+} knp_mesh_desc;
+
+/* nodal fields (device pointers, each n_vertices doubles) */
+typedef struct {
+    const double* k_i[KNP_MAX_IONS];
+    const double* k_e[KNP_MAX_IONS];
+    const double* phi_m;
+    const double* aux[KNP_MAX_AUX];
+} knp_fields;
+
+typedef struct {
+    double* k_i[KNP_MAX_IONS];
+    double* k_e[KNP_MAX_IONS];
+    double* phi_i;
+    double* phi_e;
+    double* phi_m;
+} knp_fields_out;
+
+/* indices into the array filled by knp_get_sizes */
+enum {
+    KNP_SZ_N_NODES = 0, KNP_SZ_N_NODES_OWNED = 1, KNP_SZ_N_DOF_LOCAL = 2, KNP_SZ_N_DOF_OWNED = 3,
+    KNP_SZ_NNZ = 4, KNP_SZ_N_PAIRS = 5, KNP_SZ_N_CONTRIB = 6, KNP_SZ_N_GAMMA_VERTS = 7,
+    KNP_SZ_N_GAMMA_PAIRS = 8, KNP_SZ_NNZ_P = 9, KNP_SZ_N_PHI_OWNED = 10, KNP_SZ_COUNT = 16
+};
+
+/* communication hooks (multi-GPU); both receive DEVICE pointers */
+typedef int (*knp_halo_fn)(void* user, double* x_local);              /* fill ghost part of x */
+typedef int (*knp_allreduce_fn)(void* user, double* buf, int32_t n);  /* in-place SUM over ranks */
+
+/* ---- lifetime ---- */
+int knp_create(knp_ctx** out, const knp_mesh_desc* mesh);
+int knp_destroy(knp_ctx* ctx);
+const char* knp_last_error(const knp_ctx* ctx);
+int knp_set_stream(knp_ctx* ctx, void* hip_stream);
+int knp_set_comm(knp_ctx* ctx, knp_halo_fn halo, knp_allreduce_fn allreduce, void* user);
+
+/* ---- description ---- */
+int knp_get_sizes(const knp_ctx* ctx, int64_t* sizes /* host [KNP_SZ_COUNT] */);
+int knp_get_layout(const knp_ctx* ctx, int32_t* node_i, int32_t* node_e /* host [n_vertices] each */);
+int knp_get_csr_pattern(const knp_ctx* ctx, int32_t* rowptr, int32_t* colind /* host */);
+int knp_get_csr_values(const knp_ctx* ctx, double* vals /* host [nnz] */);
+int knp_get_precond_csr(const knp_ctx* ctx, int32_t* rowptr, int32_t* colind, double* vals /* host */);
+int knp_get_device_csr(const knp_ctx* ctx, const int32_t** rowptr, const int32_t** colind, const double** vals);
+
+/* ---- problem data ---- */
+int knp_set_params(knp_ctx* ctx, double dt, double F, double C_M, double psi, int32_t n_ions,
+                   const double* z, const double* Di, const double* De);
+int knp_set_program(knp_ctx* ctx, int32_t prog_id, int32_t n_instr, const int32_t* code /* host [n_instr*4] */,
+                    int32_t n_consts, const double* consts /* host */);
+int knp_set_program_constants(knp_ctx* ctx, int32_t prog_id, int32_t n_consts, const double* consts);
+/* volumetric source terms dt*f (KNPEMIx_problem.py:613-614); NULL pointers mean zero. nodal, device. */
+int knp_set_sources(knp_ctx* ctx, const double* const* f_i, const double* const* f_e);
+
+/* ---- per-timestep assembly ---- */
+int knp_assemble_matrix(knp_ctx* ctx, const knp_fields* fields);
+int knp_assemble_rhs(knp_ctx* ctx, const knp_fields* fields, double* b /* device [n_dof_local] */);
+int knp_assemble_precond(knp_ctx* ctx, const knp_fields* fields);
+
+/* ---- linear algebra ---- */
+int knp_spmv(knp_ctx* ctx, const double* x, double* y); /* y(owned) = A x ; calls the halo hook first */
+int knp_set_nullspace(knp_ctx* ctx, int32_t on);
+int knp_project_nullspace(knp_ctx* ctx, double* v);
+int knp_nullspace_test(knp_ctx* ctx, double* out_norm /* host: ||A ns||_2 */);
+int knp_pc_setup(knp_ctx* ctx, int32_t kind);
+int knp_pc_apply(knp_ctx* ctx, const double* r, double* z);
+/* AMG hierarchy supplied level by level (level 0 = finest = P itself). All arrays HOST; copied. */
+int knp_amg_reset(knp_ctx* ctx, int32_t n_levels, int32_t pre_sweeps, int32_t post_sweeps, int32_t cheby_degree);
+int knp_amg_set_level(knp_ctx* ctx, int32_t level, int32_t n_rows, int32_t n_cols_halo,
+                      const int32_t* A_rowptr, const int32_t* A_colind, const double* A_vals,
+                      const double* inv_diag, double lambda_max,
+                      int32_t n_coarse,
+                      const int32_t* P_rowptr, const int32_t* P_colind, const double* P_vals,
+                      const int32_t* R_rowptr, const int32_t* R_colind, const double* R_vals);
+int knp_amg_set_coarse(knp_ctx* ctx, int32_t n, const double* dense_inverse /* host [n*n] row-major */);
+int knp_gmres_solve(knp_ctx* ctx, const double* b, double* x, double rtol, double atol, int32_t max_it,
+                    int32_t restart, int32_t* its, double* rnorm, int32_t* reason);
+
+/* ---- state transfer ---- */
+int knp_pack(knp_ctx* ctx, const knp_fields_out* fields, double* x);
+int knp_unpack(knp_ctx* ctx, const double* x, const knp_fields_out* fields);
+int knp_hh_update(knp_ctx* ctx, const double* phi_m, double* n, double* m, double* h, int32_t count,
+                  double dt, double phi_rest, int32_t rush_larsen, int32_t substeps);
+int knp_l2_norms(knp_ctx* ctx, const double* phi_i, const double* phi_e, double* out /* host [2]: squared, owned cells */);
+
+/* ---- instrumentation ---- */
+/* elapsed ms and launch count of a kernel class since the last reset (HIP events on the ctx stream).
+ * classes: 0 spmv, 1 orthogonalisation, 2 pc, 3 assembly, 4 other */
+int knp_profile_enable(knp_ctx* ctx, int32_t on);
+int knp_profile_get(knp_ctx* ctx, int32_t cls, double* ms, int64_t* launches);
+int knp_profile_reset(knp_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KNPEMI_HIP_H */

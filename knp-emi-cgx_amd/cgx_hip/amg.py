@@ -1,0 +1,213 @@
+"""Smoothed-aggregation AMG hierarchy for the block-diagonal preconditioner matrix P.
+
+Setup only (runs once, like ``ksp.setUp()`` with ``pc_type hypre`` in the reference,
+src/CGx/KNPEMI/KNPEMIx_solver.py:386-389): builds the level operators on the host with
+SciPy sparse products and hands them to the HIP library (``knp_amg_set_level``), which
+applies the V-cycle on the GPU with its CSR SpMV / Chebyshev kernels.
+
+P couples neither different fields nor the two sides (KNPEMIx_problem.py:717-738), so a scalar
+aggregation on P's own strength graph automatically yields one hierarchy per elliptic block
+(k_i^1..3, phi_i, k_e^1..3, phi_e) -- the "block-Jacobi" structure the reference feeds to BoomerAMG.
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+
+
+def _row_max(indptr, vals_at_cols, fill):
+    """max over each CSR row of vals_at_cols (already gathered by column); empty rows -> fill."""
+    n = indptr.size - 1
+    out = np.full(n, fill, dtype=vals_at_cols.dtype)
+    nonempty = indptr[1:] > indptr[:-1]
+    if vals_at_cols.size:
+        red = np.maximum.reduceat(vals_at_cols, indptr[:-1][nonempty])
+        out[nonempty] = red
+    return out
+
+
+def strength_graph(A: sp.csr_matrix, theta: float) -> sp.csr_matrix:
+    """Symmetric SA strength: |a_ij| >= theta*sqrt(|a_ii a_jj|), diagonal excluded."""
+    A = A.tocsr()
+    d = np.abs(A.diagonal())
+    coo = A.tocoo()
+    keep = (coo.row != coo.col) & (np.abs(coo.data) >= theta * np.sqrt(d[coo.row] * d[coo.col])) & (coo.data != 0)
+    S = sp.csr_matrix((np.ones(int(keep.sum())), (coo.row[keep], coo.col[keep])), shape=A.shape)
+    S = ((S + S.T) > 0).astype(np.float64).tocsr()
+    S.sort_indices()
+    return S
+
+
+def aggregate(S: sp.csr_matrix, seed: int = 0) -> tuple[np.ndarray, int]:
+    """Distance-2 maximal-independent-set aggregation (parallel-friendly Vanek scheme).
+
+    Roots form an MIS of S^2 (Luby rounds with fixed pseudo-random priorities), every root takes
+    its strong neighbours; leftovers join the neighbouring aggregate of highest priority; isolated
+    nodes become singletons.  Deterministic for a given seed."""
+    n = S.shape[0]
+    indptr, indices = S.indptr, S.indices
+    rng = np.random.default_rng(seed)
+    prio = rng.permutation(n).astype(np.float64) + 1.0       # unique priorities in [1, n]
+    state = np.zeros(n, dtype=np.int8)                       # 0 undecided, 1 root, 2 removed
+    for _ in range(200):
+        und = state == 0
+        if not und.any():
+            break
+        w = np.where(und, prio, 0.0)
+        m1 = np.maximum(w, _row_max(indptr, w[indices], 0.0))
+        m2 = np.maximum(m1, _row_max(indptr, m1[indices], 0.0))
+        new_root = und & (w >= m2)
+        state[new_root] = 1
+        r = new_root.astype(np.float64)
+        r1 = np.maximum(r, _row_max(indptr, r[indices], 0.0))
+        r2 = np.maximum(r1, _row_max(indptr, r1[indices], 0.0))
+        state[(state == 0) & (r2 > 0)] = 2
+    roots = np.nonzero(state == 1)[0]
+    agg = np.full(n, -1, dtype=np.int64)
+    agg[roots] = np.arange(roots.size)
+    # phase 1: strong neighbours of a root join it (distance-2 independence => no conflicts)
+    rootid = np.where(state == 1, agg, -1).astype(np.float64)
+    nb = _row_max(indptr, rootid[indices], -1.0)
+    take = (agg < 0) & (nb >= 0)
+    agg[take] = nb[take].astype(np.int64)
+    # phase 2: remaining nodes join the aggregate of their highest-priority aggregated neighbour
+    for _ in range(3):
+        left = agg < 0
+        if not left.any():
+            break
+        key = np.where(agg >= 0, prio, -1.0)
+        best = _row_max(indptr, key[indices], -1.0)
+        # find which neighbour achieved the max: priorities are unique -> map priority -> node
+        node_of_prio = np.empty(n + 2, dtype=np.int64)
+        node_of_prio[prio.astype(np.int64)] = np.arange(n)
+        ok = left & (best > 0)
+        agg[ok] = agg[node_of_prio[best[ok].astype(np.int64)]]
+    left = np.nonzero(agg < 0)[0]
+    nagg = roots.size
+    if left.size:
+        agg[left] = nagg + np.arange(left.size)
+        nagg += left.size
+    return agg, int(nagg)
+
+
+def estimate_lambda_max(A: sp.csr_matrix, dinv: np.ndarray, iters: int = 20, seed: int = 1) -> float:
+    """Power iteration on D^{-1} A (largest magnitude eigenvalue), padded by 5 %."""
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal(A.shape[0])
+    x /= np.linalg.norm(x)
+    lam = 1.0
+    for _ in range(iters):
+        y = dinv * (A @ x)
+        lam = float(np.linalg.norm(y))
+        if lam == 0.0:
+            return 1.0
+        x = y / lam
+    return 1.05 * lam
+
+
+class Level:
+    __slots__ = ("A", "dinv", "lambda_max", "P", "R")
+
+    def __init__(self, A, dinv, lambda_max, P=None, R=None):
+        self.A, self.dinv, self.lambda_max, self.P, self.R = A, dinv, lambda_max, P, R
+
+
+class Hierarchy:
+    def __init__(self, levels, coarse_inv):
+        self.levels = levels
+        self.coarse_inv = coarse_inv
+
+    def describe(self):
+        rows = [lv.A.shape[0] for lv in self.levels]
+        nnz = [lv.A.nnz for lv in self.levels]
+        return {"rows": rows, "nnz": nnz,
+                "operator_complexity": float(sum(nnz)) / max(nnz[0], 1),
+                "grid_complexity": float(sum(rows)) / max(rows[0], 1)}
+
+
+def build_hierarchy(P: sp.csr_matrix, theta: float = 0.08, max_levels: int = 12, coarse_size: int = 1200,
+                    smooth_prolongator: bool = True) -> Hierarchy:
+    A = sp.csr_matrix(P, dtype=np.float64)
+    A.sort_indices()
+    levels = []
+    while True:
+        diag = A.diagonal()
+        dinv = np.where(diag != 0.0, 1.0 / np.where(diag != 0.0, diag, 1.0), 0.0)
+        lam = estimate_lambda_max(A, dinv)
+        n = A.shape[0]
+        if n <= coarse_size or len(levels) >= max_levels - 1:
+            levels.append(Level(A, dinv, lam))
+            break
+        S = strength_graph(A, theta)
+        agg, nagg = aggregate(S, seed=len(levels))
+        if nagg >= 0.9 * n:                                   # coarsening stalled
+            levels.append(Level(A, dinv, lam))
+            break
+        T = sp.csr_matrix((np.ones(n), (np.arange(n), agg)), shape=(n, nagg))
+        if smooth_prolongator:
+            # filtered matrix: weak off-diagonals lumped onto the diagonal
+            Sp = S + sp.identity(n, format="csr")
+            AF = A.multiply(Sp).tocsr()
+            lump = np.asarray(A.sum(axis=1)).ravel() - np.asarray(AF.sum(axis=1)).ravel()
+            AF = AF + sp.diags(lump)
+            dF = AF.diagonal()
+            dFinv = np.where(dF != 0.0, 1.0 / np.where(dF != 0.0, dF, 1.0), 0.0)
+            lamF = estimate_lambda_max(AF.tocsr(), dFinv, iters=15)
+            omega = 4.0 / (3.0 * lamF)
+            Pm = (T - sp.diags(omega * dFinv) @ (AF @ T)).tocsr()
+        else:
+            Pm = T
+        Pm.sort_indices()
+        R = Pm.T.tocsr()
+        R.sort_indices()
+        Ac = (R @ (A @ Pm)).tocsr()
+        Ac.sort_indices()
+        levels.append(Level(A, dinv, lam, Pm, R))
+        A = Ac
+    Ad = levels[-1].A.toarray()
+    if Ad.shape[0] <= 4000:
+        coarse_inv = np.linalg.pinv(Ad, rcond=1e-13)
+    else:
+        coarse_inv = None
+    return Hierarchy(levels, coarse_inv)
+
+
+def upload(lib, ctx, check, hier: Hierarchy, pre: int = 1, post: int = 1, cheby_degree: int = 2):
+    """Hand the hierarchy to libknpemi_hip (host arrays are copied by the library)."""
+    import ctypes as C
+    i32p = C.POINTER(C.c_int32)
+    f64p = C.POINTER(C.c_double)
+
+    def ip(a):
+        return a.ctypes.data_as(i32p)
+
+    def fp(a):
+        return a.ctypes.data_as(f64p)
+
+    nl = len(hier.levels)
+    check(lib.knp_amg_reset(ctx, nl, pre, post, cheby_degree))
+    keep = []
+    for l, lv in enumerate(hier.levels):
+        A = lv.A
+        rp = np.ascontiguousarray(A.indptr, dtype=np.int32)
+        ci = np.ascontiguousarray(A.indices, dtype=np.int32)
+        va = np.ascontiguousarray(A.data, dtype=np.float64)
+        dinv = np.ascontiguousarray(lv.dinv, dtype=np.float64)
+        keep += [rp, ci, va, dinv]
+        if lv.P is not None:
+            Prp = np.ascontiguousarray(lv.P.indptr, dtype=np.int32)
+            Pci = np.ascontiguousarray(lv.P.indices, dtype=np.int32)
+            Pv = np.ascontiguousarray(lv.P.data, dtype=np.float64)
+            Rrp = np.ascontiguousarray(lv.R.indptr, dtype=np.int32)
+            Rci = np.ascontiguousarray(lv.R.indices, dtype=np.int32)
+            Rv = np.ascontiguousarray(lv.R.data, dtype=np.float64)
+            keep += [Prp, Pci, Pv, Rrp, Rci, Rv]
+            check(lib.knp_amg_set_level(ctx, l, A.shape[0], A.shape[0], ip(rp), ip(ci), fp(va), fp(dinv),
+                                        float(lv.lambda_max), lv.P.shape[1], ip(Prp), ip(Pci), fp(Pv),
+                                        ip(Rrp), ip(Rci), fp(Rv)))
+        else:
+            check(lib.knp_amg_set_level(ctx, l, A.shape[0], A.shape[0], ip(rp), ip(ci), fp(va), fp(dinv),
+                                        float(lv.lambda_max), 0, None, None, None, None, None, None))
+    if hier.coarse_inv is not None:
+        ci_ = np.ascontiguousarray(hier.coarse_inv, dtype=np.float64)
+        check(lib.knp_amg_set_coarse(ctx, ci_.shape[0], fp(ci_)))

@@ -1,0 +1,283 @@
+"""Per-rank handle on libknpemi_hip: owns the ``knp_ctx`` and the torch tensors (device memory) that
+back the block vectors.  Everything numerical goes through the C ABI (include/knpemi_hip.h)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Fields, FieldsOut, KnpError, MeshDesc
+from .parallel import HaloPlan, all_reduce_sum_, guarded
+
+
+class _CAI:
+    """Expose a raw HIP pointer through __cuda_array_interface__ so torch can view it."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def _f64(a):
+    return a.ctypes.data_as(_lib.f64p)
+
+
+def _i32(a):
+    return a.ctypes.data_as(_lib.i32p)
+
+
+class Backend:
+    def __init__(self, problem):
+        self.p = problem
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise KnpError("No HIP device visible: the KNP-EMI assemble-and-solve path runs on the GPU only "
+                           "(there is deliberately no CPU fallback).")
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        lm = problem.local_mesh
+        dim = lm.coords.shape[1]
+        self._keep = []
+        coords = np.ascontiguousarray(lm.coords, dtype=np.float64)
+        cells = np.ascontiguousarray(lm.cells, dtype=np.int32)
+        side = np.ascontiguousarray(problem.cell_side, dtype=np.uint8)
+        gamma = np.ascontiguousarray(lm.gamma, dtype=np.int32)
+        tag_index = {t: k for k, t in enumerate(problem.gamma_tags)}
+        gprog = np.ascontiguousarray([tag_index[int(t)] for t in lm.gamma_tags], dtype=np.int32)
+        qp = np.ascontiguousarray(problem.q_pts, dtype=np.float64)
+        qw = np.ascontiguousarray(problem.q_w, dtype=np.float64)
+        self._keep += [coords, cells, side, gamma, gprog, qp, qw]
+        desc = MeshDesc()
+        desc.dim = dim
+        desc.n_vertices = coords.shape[0]
+        desc.n_vertices_owned = lm.n_vertices_owned
+        desc.n_cells = cells.shape[0]
+        desc.n_cells_owned = lm.n_cells_owned
+        desc.cells = _i32(cells)
+        desc.coords = _f64(coords)
+        desc.cell_side = side.ctypes.data_as(_lib.u8p)
+        desc.n_gamma = gamma.shape[0]
+        desc.gamma = _i32(gamma) if gamma.size else None
+        desc.gamma_prog = _i32(gprog) if gprog.size else None
+        desc.n_q = qw.shape[0]
+        desc.q_pts = _f64(qp)
+        desc.q_w = _f64(qw)
+        ctx = C.c_void_p()
+        rc = self.lib.knp_create(C.byref(ctx), C.byref(desc))
+        self.ctx = ctx
+        if rc != 0:
+            msg = self.lib.knp_last_error(ctx) if ctx else b"allocation failed"
+            if ctx:
+                self.lib.knp_destroy(ctx)
+                self.ctx = None
+            raise KnpError(f"knp_create failed ({rc}): {msg.decode()}")
+        self.check(self.lib.knp_set_stream(self.ctx, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        sz = (C.c_int64 * _lib.KNP_SZ_COUNT)()
+        self.check(self.lib.knp_get_sizes(self.ctx, sz))
+        self.sizes = list(sz)
+        self.n_nodes = sz[_lib.SZ_N_NODES]
+        self.n_nodes_owned = sz[_lib.SZ_N_NODES_OWNED]
+        self.n_dof_local = sz[_lib.SZ_N_DOF_LOCAL]
+        self.n_dof_owned = sz[_lib.SZ_N_DOF_OWNED]
+        self.nnz = sz[_lib.SZ_NNZ]
+        self.n_pairs = sz[_lib.SZ_N_PAIRS]
+        self.n_contrib = sz[_lib.SZ_N_CONTRIB]
+        self.node_i = np.empty(desc.n_vertices, dtype=np.int32)
+        self.node_e = np.empty(desc.n_vertices, dtype=np.int32)
+        self.check(self.lib.knp_get_layout(self.ctx, _i32(self.node_i), _i32(self.node_e)))
+        self.n_dof_global = int(problem.comm.allreduce_sum(self.n_dof_owned))
+        self.nnz_global = int(problem.comm.allreduce_sum(self.nnz))
+        self.set_params()
+        # block vectors
+        self.b = torch.zeros(self.n_dof_local, dtype=torch.float64, device=self.device)
+        self.x = torch.zeros(self.n_dof_local, dtype=torch.float64, device=self.device)
+        # communication hooks
+        self.halo = HaloPlan(problem.comm, lm, self.node_i, self.node_e, self.device)
+        self._views = {}
+        if problem.comm.size > 1:
+            self._halo_cb = _lib.HALO_FN(guarded(self._halo))
+            self._ar_cb = _lib.ALLREDUCE_FN(guarded(self._allreduce))
+            self.check(self.lib.knp_set_comm(self.ctx, self._halo_cb, self._ar_cb, None))
+        if getattr(problem, "programs", None):
+            self.upload_programs()
+
+    # ------------------------------------------------------------------ helpers
+    def check(self, rc):
+        _lib.check(self.ctx, rc)
+
+    def __del__(self):
+        try:
+            if getattr(self, "ctx", None):
+                self.lib.knp_destroy(self.ctx)
+                self.ctx = None
+        except Exception:      # noqa: BLE001
+            pass
+
+    def _view(self, ptr, n):
+        key = (int(ptr), int(n))
+        t = self._views.get(key)
+        if t is None:
+            t = torch.as_tensor(_CAI(ptr, n), device=self.device)
+            if len(self._views) > 256:
+                self._views.clear()
+            self._views[key] = t
+        return t
+
+    def _halo(self, user, xptr):
+        self.halo.exchange(self._view(xptr, self.n_dof_local))
+
+    def _allreduce(self, user, ptr, n):
+        all_reduce_sum_(self._view(ptr, n), self.p.comm)
+
+    def set_params(self):
+        p = self.p
+        z = np.array([float(ion["z"].value) for ion in p.ion_list], dtype=np.float64)
+        Di = np.array([float(ion["Di"].value) for ion in p.ion_list], dtype=np.float64)
+        De = np.array([float(ion["De"].value) for ion in p.ion_list], dtype=np.float64)
+        self.check(self.lib.knp_set_params(self.ctx, float(p.dt.value), float(p.F.value), float(p.C_M.value),
+                                           float(p.psi.value), len(p.ion_list), _f64(z), _f64(Di), _f64(De)))
+
+    def upload_programs(self):
+        for pid, spec in self.p.programs.items():
+            code = np.ascontiguousarray(spec.code, dtype=np.int32)
+            consts = spec.constants()
+            self.check(self.lib.knp_set_program(self.ctx, int(pid), code.shape[0], _i32(code), consts.shape[0],
+                                                _f64(consts) if consts.size else None))
+        self._programs_uploaded = True
+
+    def refresh_program_constants(self):
+        for pid, spec in self.p.programs.items():
+            consts = spec.constants()
+            if consts.size:
+                self.check(self.lib.knp_set_program_constants(self.ctx, int(pid), consts.shape[0], _f64(consts)))
+
+    def fields(self):
+        p = self.p
+        f = Fields()
+        for j in range(3):
+            f.k_i[j] = p.wh[0][j].data_ptr()
+            f.k_e[j] = p.wh[1][j].data_ptr()
+        f.phi_m = p.phi_m_prev.data_ptr()
+        for k, fn in enumerate(getattr(p, "aux_functions", [])):
+            f.aux[k] = fn.data_ptr()
+        return f
+
+    def fields_out(self):
+        p = self.p
+        f = FieldsOut()
+        for j in range(3):
+            f.k_i[j] = p.wh[0][j].data_ptr()
+            f.k_e[j] = p.wh[1][j].data_ptr()
+        f.phi_i = p.wh[0][3].data_ptr()
+        f.phi_e = p.wh[1][3].data_ptr()
+        f.phi_m = p.phi_m_prev.data_ptr()
+        return f
+
+    # ------------------------------------------------------------------ operations
+    def assemble_matrix(self):
+        f = self.fields()
+        self.check(self.lib.knp_assemble_matrix(self.ctx, C.byref(f)))
+
+    def assemble_rhs(self):
+        if not getattr(self, "_programs_uploaded", False):
+            self.upload_programs()
+        self.refresh_program_constants()
+        f = self.fields()
+        self.check(self.lib.knp_assemble_rhs(self.ctx, C.byref(f), C.c_void_p(self.b.data_ptr())))
+
+    def assemble_precond(self):
+        f = self.fields()
+        self.check(self.lib.knp_assemble_precond(self.ctx, C.byref(f)))
+
+    def pack(self):
+        f = self.fields_out()
+        self.check(self.lib.knp_pack(self.ctx, C.byref(f), C.c_void_p(self.x.data_ptr())))
+
+    def unpack(self):
+        f = self.fields_out()
+        self.check(self.lib.knp_unpack(self.ctx, C.c_void_p(self.x.data_ptr()), C.byref(f)))
+
+    def hh_update(self, phi_m, n, m, h, dt, phi_rest, rush_larsen, substeps):
+        self.check(self.lib.knp_hh_update(self.ctx, C.c_void_p(phi_m.data_ptr()), C.c_void_p(n.data_ptr()),
+                                          C.c_void_p(m.data_ptr()), C.c_void_p(h.data_ptr()),
+                                          int(phi_m.x.array.numel()), dt, phi_rest, int(rush_larsen), int(substeps)))
+
+    def set_nullspace(self, on=True):
+        self.check(self.lib.knp_set_nullspace(self.ctx, 1 if on else 0))
+
+    def project_nullspace(self, vec: torch.Tensor):
+        self.check(self.lib.knp_project_nullspace(self.ctx, C.c_void_p(vec.data_ptr())))
+
+    def nullspace_test(self) -> float:
+        out = C.c_double()
+        self.check(self.lib.knp_nullspace_test(self.ctx, C.byref(out)))
+        return out.value
+
+    def pc_setup(self, kind):
+        self.check(self.lib.knp_pc_setup(self.ctx, int(kind)))
+
+    def pc_apply(self, r: torch.Tensor, z: torch.Tensor):
+        self.check(self.lib.knp_pc_apply(self.ctx, C.c_void_p(r.data_ptr()), C.c_void_p(z.data_ptr())))
+
+    def spmv(self, x: torch.Tensor, y: torch.Tensor):
+        self.check(self.lib.knp_spmv(self.ctx, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr())))
+
+    def gmres(self, rtol, atol=1e-50, max_it=5000, restart=30):
+        its = C.c_int32()
+        rn = C.c_double()
+        reason = C.c_int32()
+        self.check(self.lib.knp_gmres_solve(self.ctx, C.c_void_p(self.b.data_ptr()), C.c_void_p(self.x.data_ptr()),
+                                            float(rtol), float(atol), int(max_it), int(restart), C.byref(its),
+                                            C.byref(rn), C.byref(reason)))
+        return its.value, rn.value, reason.value
+
+    def l2_norms_sq(self):
+        out = (C.c_double * 2)()
+        p = self.p
+        self.check(self.lib.knp_l2_norms(self.ctx, C.c_void_p(p.wh[0][3].data_ptr()), C.c_void_p(p.wh[1][3].data_ptr()), out))
+        return p.comm.allreduce_sum(out[0]), p.comm.allreduce_sum(out[1])
+
+    def total_ion_amounts(self):
+        raise NotImplementedError
+
+    # ---- exports (parity hooks) ------------------------------------------------------------
+    def csr(self):
+        """A as scipy CSR (rows = owned DoFs, cols = local DoFs), columns sorted."""
+        import scipy.sparse as sp
+        rp = np.empty(self.n_dof_owned + 1, dtype=np.int32)
+        ci = np.empty(self.nnz, dtype=np.int32)
+        va = np.empty(self.nnz, dtype=np.float64)
+        self.check(self.lib.knp_get_csr_pattern(self.ctx, _i32(rp), _i32(ci)))
+        self.check(self.lib.knp_get_csr_values(self.ctx, _f64(va)))
+        A = sp.csr_matrix((va, ci, rp), shape=(self.n_dof_owned, self.n_dof_local))
+        A.sort_indices()
+        return A
+
+    def precond_csr(self):
+        import scipy.sparse as sp
+        nnzp = self.sizes[_lib.SZ_NNZ_P]
+        rp = np.empty(self.n_dof_owned + 1, dtype=np.int32)
+        ci = np.empty(nnzp, dtype=np.int32)
+        va = np.empty(nnzp, dtype=np.float64)
+        self.check(self.lib.knp_get_precond_csr(self.ctx, _i32(rp), _i32(ci), _f64(va)))
+        P = sp.csr_matrix((va, ci, rp), shape=(self.n_dof_owned, self.n_dof_local))
+        P.sort_indices()
+        return P
+
+    # ---- instrumentation -----------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self.check(self.lib.knp_profile_enable(self.ctx, 1 if on else 0))
+
+    def profile_reset(self):
+        self.check(self.lib.knp_profile_reset(self.ctx))
+
+    def profile_get(self):
+        names = ["spmv", "orthogonalisation", "pc", "assembly", "other"]
+        out = {}
+        for k, nm in enumerate(names):
+            ms = C.c_double()
+            n = C.c_int64()
+            self.check(self.lib.knp_profile_get(self.ctx, k, C.byref(ms), C.byref(n)))
+            out[nm] = (ms.value, n.value)
+        return out

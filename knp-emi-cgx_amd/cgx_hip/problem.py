@@ -1,0 +1,584 @@
+"""``MixedDimensionalProblem`` / ``ProblemKNPEMI``: the reference's problem-definition surface on top
+of the MI355X-native backend.
+
+Mirrors (names, constructor, attributes, call order) reference
+  src/CGx/utils/mixed_dim_problem.py   (YAML schema :86-374, tags :376-433, ionic models :435-465,
+                                        domain / '+'=intra ordering :634-733)
+  src/CGx/KNPEMI/KNPEMIx_problem.py    (spaces/restrictions :28-94, ICs :220-452, forms :454-655,
+                                        preconditioner :657-744, constants :909-981)
+What differs by design: there is no UFL/FFCx/DOLFINx.  ``setup_variational_form`` compiles the
+membrane currents of the registered mechanisms to bytecode programs for the HIP membrane kernel;
+the block forms a, L, P themselves are hard-wired in the HIP assembly kernels
+(knp-emi-cgx_amd/csrc/knp_kernels.hip), which restate KNPEMIx_problem.py:586-642 and :717-738.
+"""
+from __future__ import annotations
+
+import collections.abc
+import ctypes as C
+import os
+import pathlib
+import time
+from abc import ABC, abstractmethod
+
+import numpy as np
+import torch
+import yaml
+
+from . import _lib, fem
+from . import mesh as meshmod
+from .fem import Constant, Function, FunctionSpace
+from .parallel import Comm, LocalMesh, partition_mesh
+
+
+def range_constructor(loader, node):
+    """``!range [a, b]`` YAML tag (reference src/CGx/utils/misc.py:33-37)."""
+    args = loader.construct_sequence(node)
+    return list(range(*args))
+
+
+def flatten_list(input_list):
+    return [item for sublist in input_list for item in (sublist if isinstance(sublist, tuple) else [sublist])]
+
+
+class _Measure:
+    """Placeholder for ufl.Measure so that ``problem.dx(tags)`` / ``problem.dS(tags)`` stay callable;
+    integration itself happens in the HIP kernels."""
+
+    def __init__(self, kind, degree=10):
+        self.kind, self.degree, self.tags = kind, degree, None
+
+    def __call__(self, tags=None):
+        m = _Measure(self.kind, self.degree)
+        m.tags = tags
+        return m
+
+
+class MixedDimensionalProblem(ABC):
+
+    def __init__(self, config_file: str, comm: Comm | None = None, local_mesh: LocalMesh | None = None):
+        tic = time.perf_counter()
+        self.comm = comm if comm is not None else Comm()
+        self._local_mesh_override = local_mesh
+        self.read_config_file(config_file=config_file)
+        self.print("Read input data from " + (str(config_file) if not isinstance(config_file, dict) else "<dict>"))
+        self.setup_domain()
+        self.t = Constant(self.mesh, 0.0)
+        self.dt = Constant(self.mesh, self.dt)
+        self.setup_constants()
+        self.setup_spaces()
+        self.init()
+        self.setup_boundary_conditions()
+        if self.source_terms == "ion_injection":
+            self.setup_source_terms()
+        self.ionic_models = []
+        self.backend = None
+        self.print(f"Problem setup in {time.perf_counter() - tic:0.4f} seconds.\n")
+
+    def print(self, *a, **k):
+        if self.comm.rank == 0 and not getattr(self, "quiet", False):
+            print(*a, **k, flush=True)
+
+    @abstractmethod
+    def init(self): ...
+    @abstractmethod
+    def setup_spaces(self): ...
+    @abstractmethod
+    def setup_boundary_conditions(self): ...
+    @abstractmethod
+    def setup_source_terms(self): ...
+    @abstractmethod
+    def setup_constants(self): ...
+
+    # ---------------------------------------------------------------- config (schema of :86-374)
+    def read_config_file(self, config_file):
+        yaml.add_constructor("!range", range_constructor, Loader=yaml.FullLoader)
+        if isinstance(config_file, dict):
+            config = config_file
+        else:
+            with open(config_file, "r") as file:
+                config = yaml.load(file, Loader=yaml.FullLoader)
+        self.config = config
+        self.quiet = bool(config.get("quiet", False))
+        if "solver" in config:
+            self.solver_config: dict = config["solver"]
+        else:
+            raise RuntimeError("Provide solver configuration in input file.")
+        input_dir = config.get("input_dir", "./")
+        if "output_dir" in config:
+            self.output_dir = config["output_dir"]
+        else:
+            self.output_dir = "./output/"
+        if any(self.solver_config.get("output", {}).get(k, False) for k in ("save_xdmf", "save_pngs", "save_cpoints", "save_dat", "save_mat")):
+            pathlib.Path(self.output_dir).mkdir(parents=True, exist_ok=True)
+        if "cell_tag_file" in config and "facet_tag_file" in config:
+            self.input_files = {"mesh_file": input_dir + config["cell_tag_file"],
+                                "facet_file": input_dir + config["facet_tag_file"]}
+        else:
+            raise RuntimeError("Provide cell_tag_file and facet_tag_file fields in input file.")
+        if "dt" in config:
+            self.dt = float(config["dt"])
+        else:
+            raise RuntimeError("Provide dt (timestep size) field in input file.")
+        if "time_steps" in config:
+            self.time_steps = int(config["time_steps"])
+        elif "T" in config:
+            self.time_steps = int(float(config["T"]) / float(config["dt"]))
+        else:
+            raise RuntimeError("Provide final time T or time_steps field in input file.")
+
+        tags = {}
+        if "ics_tags" in config:
+            tags["intra"] = config["ics_tags"]
+        else:
+            raise RuntimeError("Provide ics_tags (intracellular space tags) field in input file.")
+        if "ecs_tags" in config: tags["extra"] = config["ecs_tags"]
+        if "boundary_tags" in config: tags["boundary"] = config["boundary_tags"]
+        if "membrane_tags" in config: tags["membrane"] = config["membrane_tags"]
+        if "stimulus_tags" in config:
+            self.stimulus_tags = config["stimulus_tags"]
+        else:
+            self.stimulus_tags = tags.get("membrane", tags["intra"])
+        if "glia_tags" in config:
+            tags["glia"] = config["glia_tags"]
+            tags["neuron"] = [t for t in _aslist(tags["intra"]) if t not in tags["glia"]]
+        else:
+            tags["neuron"] = tags["intra"]
+        self.parse_tags(tags=tags)
+
+        if "physical_constants" in config:
+            consts = config["physical_constants"]
+            self.T_value = float(consts.get("T", 1.0))
+            self.R_value = float(consts.get("R", 1.0))
+            self.F_value = float(consts.get("F", 1.0))
+            self.psi_value = self.R_value * self.T_value / self.F_value
+        else:
+            self.T_value = self.R_value = self.F_value = self.psi_value = 1.0
+        self.C_M_value = float(config.get("C_M", 1.0))
+        if "mesh_conversion_factor" in config:
+            self.mesh_conversion_factor = float(config["mesh_conversion_factor"])
+        if "fem_order" in config:
+            self.fem_order = int(config["fem_order"])
+            if self.fem_order != 1:
+                raise RuntimeError("The MI355X-native path implements P1 elements only (fem_order: 1).")
+        if "dirichlet_bcs" in config:
+            self.dirichlet_bcs = bool(config["dirichlet_bcs"])
+        if "MMS_test" in config:
+            raise NotImplementedError("MMS_test configs are not supported yet by the MI355X-native path (SURVEY 8f-1).")
+        if self.dirichlet_bcs:
+            raise NotImplementedError("dirichlet_bcs: True is not supported yet by the MI355X-native path; "
+                                      "the hot path implements the pure-Neumann case (null-space gauge).")
+        self.source_terms = config.get("source_terms", None)
+        if self.source_terms is not None:
+            raise NotImplementedError("source_terms are not supported yet by the MI355X-native path (SURVEY 8f-3).")
+        self.point_evaluation = False
+        self.gamma_points = None
+
+        if "stimulus" in config:
+            try:
+                g_dict = config["stimulus"]["conductance"]
+                self.g_syn_bar_val = float(g_dict["g_syn_bar"])
+                self.a_syn_val = float(config["stimulus"]["a_syn"])
+                self.T_stim_val = float(config["stimulus"]["T_stim"])
+            except Exception:
+                raise RuntimeError("For stimulus, provide g_syn_bar, a_syn and T_stim in input file.")
+            if "tau_syn_rise" in config["stimulus"] or "tau_syn_decay" in config["stimulus"]:
+                try:
+                    self.tau_syn_rise = float(config["stimulus"]["tau_syn_rise"])
+                    self.tau_syn_decay = float(config["stimulus"]["tau_syn_decay"])
+                except Exception:
+                    raise RuntimeError("For rise and decay stimulus, provide tau_syn_rise and tau_syn_decay in input file.")
+            if "scale" in config["stimulus"]:
+                self.scale_stimulus = bool(config["stimulus"]["scale"])
+            else:
+                raise RuntimeError("Provide whether to scale stimulus strength by surface area in stimulus configuration in input file.")
+            self.g_Na_bar_val = float(g_dict.get("g_Na_bar", 1200.0))
+            self.g_K_bar_val = float(g_dict.get("g_K_bar", 360.0))
+            self.g_Na_leak_val = float(g_dict.get("g_Na_leak", 0.3))
+            self.g_Na_leak_g_val = float(g_dict.get("g_Na_leak_g", 1.0))
+            self.g_K_leak_val = float(g_dict.get("g_K_leak", 0.1))
+            self.g_K_leak_g_val = float(g_dict.get("g_K_leak_g", 16.96))
+            self.g_Cl_leak_val = float(g_dict.get("g_Cl_leak", 0.25))
+            self.g_Cl_leak_g_val = float(g_dict.get("g_Cl_leak_g", 2.0))
+        else:
+            self.g_syn_bar_val, self.a_syn_val, self.T_stim_val, self.scale_stimulus = 40.0, 5e-4, 1.0, False
+            self.g_Na_bar_val, self.g_K_bar_val = 1200.0, 360.0
+            self.g_Na_leak_val, self.g_Na_leak_g_val = 1.0, 1.0
+            self.g_K_leak_val, self.g_K_leak_g_val = 4.0, 16.96
+            self.g_Cl_leak_val, self.g_Cl_leak_g_val = 0.25, 0.50
+
+        if "stimulus_region" in config:
+            self.stimulus_region = True
+            self.stimulus_region_range = np.array(config["stimulus_region"]["range"]) * self.mesh_conversion_factor
+            axes = {"x": 0, "y": 1, "z": 2}
+            if config["stimulus_region"].get("multiple", False):
+                self.multiple_stimulus_directions = True
+                self.stimulus_region_directions = [axes[str(d)] for d in config["stimulus_region"]["direction"]]
+            else:
+                self.multiple_stimulus_directions = False
+                self.stimulus_region_direction = axes[str(config["stimulus_region"]["direction"])]
+        else:
+            self.stimulus_region = False
+            self.multiple_stimulus_directions = False
+
+        if "initial_conditions" in config:
+            self.initial_conditions = config["initial_conditions"]
+            self.find_initial_conditions = False
+        else:
+            raise NotImplementedError("Configs without 'initial_conditions' need the reference's 0-D ODE pre-processor "
+                                      "(membrane_ODE_systems.py), which is out of scope of the native hot path.")
+        if "membrane_data_tag" in config:
+            self.membrane_data_tag = int(config["membrane_data_tag"])
+        else:
+            self.membrane_data_tag = self.stimulus_tags[0] if len(self.stimulus_tags) > 0 else self.gamma_tags[0]
+
+    def parse_tags(self, tags: dict):
+        allowed = {"intra", "extra", "membrane", "boundary", "glia", "neuron"}
+        if not set(tags.keys()).issubset(allowed):
+            raise ValueError(f"Mismatch in tags.\nAllowed tags: {allowed}\nInput tags: {set(tags.keys())}")
+        if isinstance(tags["intra"], collections.abc.Sequence):
+            self.print(f"# Cell tags = {len(tags['intra'])}.")
+        else:
+            self.print("Single cell tag.")
+        self.intra_tags = tags["intra"]
+        self.extra_tag = tags.get("extra", 1)
+        self.gamma_tags = tags.get("membrane", self.intra_tags)
+        if "glia" in tags:
+            self.glia_tags = tags["glia"]
+            self.glia_flag = len(self.glia_tags) > 0
+        else:
+            self.glia_tags, self.glia_flag = None, False
+        self.neuron_tags = tags["neuron"]
+        self.boundary_tags = tags.get("boundary", 1)
+        self.intra_tags = tuple(_aslist(self.intra_tags))
+        self.extra_tag = tuple(_aslist(self.extra_tag))
+        self.boundary_tags = tuple(_aslist(self.boundary_tags))
+        self.gamma_tags = tuple(_aslist(self.gamma_tags))
+        self.neuron_tags = tuple(_aslist(self.neuron_tags))
+        self.stimulus_tags = tuple(_aslist(self.stimulus_tags))
+        if self.glia_flag:
+            self.glia_tags = tuple(_aslist(self.glia_tags))
+
+    def init_ionic_models(self, ionic_models):
+        """reference mixed_dim_problem.py:435-465"""
+        from .ionic_models import HodgkinHuxley, IonicModel
+        if isinstance(ionic_models, IonicModel):
+            ionic_models = [ionic_models]
+        self.ionic_models = ionic_models
+        self.gating_variables = False
+        ionic_tags = set()
+        for model in self.ionic_models:
+            model._init()
+            for tag in model.tags:
+                ionic_tags.add(tag)
+            self.print("Added tags for ionic model: ", str(model))
+            if isinstance(model, HodgkinHuxley):
+                self.gating_variables = True
+                self.print("Gating variables flag set to True.")
+        ionic_tags = sorted(ionic_tags)
+        gamma_tags = sorted(flatten_list([self.gamma_tags]))
+        if ionic_tags != gamma_tags and not self.MMS_test and len(ionic_tags) != 0:
+            raise RuntimeError("Mismatch between membrane tags and ionic models tags."
+                               + f"\nIonic models tags: {ionic_tags}\nMembrane tags: {gamma_tags}")
+        self.print("# Membrane tags = ", len(gamma_tags))
+        self.print("# Ionic models  = ", len(self.ionic_models), "\n")
+
+    # ---------------------------------------------------------------- domain (:634-733)
+    def setup_domain(self):
+        self.print("Setting up mesh ...")
+        if self._local_mesh_override is not None:
+            lm = self._local_mesh_override
+            self.mesh_description = lm.description
+        else:
+            coords, cells, cell_tags, facet_tags, desc = meshmod.load_mesh(
+                self.input_files["mesh_file"], self.input_files["facet_file"], self.mesh_conversion_factor)
+            self.mesh_description = desc
+            if np.all(np.array(self.intra_tags) < np.array(self.extra_tag).min()) or \
+               np.all(np.array(self.intra_tags) > np.array(self.extra_tag).max()):
+                pass
+            else:
+                raise RuntimeError("Intracellular tags must be all smaller or all larger than extracellular tag.")
+            gamma, gtags, gverts = meshmod.gamma_integration_entities(cells, cell_tags, self.intra_tags, self.extra_tag, facet_tags)
+            keep = np.isin(gtags, self.gamma_tags)
+            gamma, gtags = gamma[keep], gtags[keep]
+            lm = partition_mesh(coords, cells, cell_tags, gamma, gtags, self.comm.size, self.comm.rank)
+            lm.description = desc
+        self.local_mesh = lm
+        self.mesh = meshmod.Mesh(lm.coords, lm.cells)
+        self.mesh.comm = self.comm
+        self.subdomains = meshmod.MeshTags(self.mesh.topology.dim, np.arange(lm.cells.shape[0]), lm.cell_tags, "ct")
+        self.gamma_entities = lm.gamma
+        self.gamma_facet_tags = lm.gamma_tags
+        self.boundaries = meshmod.MeshTags(self.mesh.topology.dim - 1, np.arange(lm.gamma.shape[0]), lm.gamma_tags, "ft")
+        self.cell_side = np.where(np.isin(lm.cell_tags, self.intra_tags), 0, 1).astype(np.uint8)
+        known = np.isin(lm.cell_tags, self.intra_tags) | np.isin(lm.cell_tags, self.extra_tag)
+        if not known.all():
+            raise RuntimeError("Mesh contains cell tags that are neither ics_tags nor ecs_tags.")
+        self.dx = _Measure("dx")
+        self.dS = _Measure("dS")
+        self.q_pts, self.q_w = meshmod.facet_quadrature(self.mesh.geometry.dim, 10)
+        # facet vertices / measures on the host for setup-time membrane integrals
+        d = self.mesh.geometry.dim
+        loc = np.array([[a for a in range(d + 1) if a != lf] for lf in range(d + 1)])
+        if lm.gamma.shape[0]:
+            self._fv = lm.cells[lm.gamma[:, 0][:, None], loc[lm.gamma[:, 1]]]
+            X = lm.coords[self._fv]
+            if d == 2:
+                self._fmeas = np.linalg.norm(X[:, 1] - X[:, 0], axis=1)
+            else:
+                self._fmeas = 0.5 * np.linalg.norm(np.cross(X[:, 1] - X[:, 0], X[:, 2] - X[:, 0]), axis=1)
+        else:
+            self._fv = np.zeros((0, d), dtype=np.int32)
+            self._fmeas = np.zeros(0)
+        self.neuron_cells = np.nonzero(np.isin(lm.cell_tags, self.neuron_tags))[0]
+        if self.glia_flag:
+            self.glia_cells = np.nonzero(np.isin(lm.cell_tags, self.glia_tags))[0]
+
+    def integrate_over_membrane(self, integrand, tags):
+        """assemble_scalar(integrand * dS(tags)) summed over ranks (setup-time only; each membrane
+        facet is counted by the rank owning its first vertex)."""
+        sel = np.isin(self.gamma_facet_tags, tags) & (self._fv[:, 0] < self.local_mesh.n_vertices_owned if len(self._fv) else np.zeros(0, bool))
+        fv = self._fv[sel]
+        if isinstance(integrand, (int, float)):
+            val = float(integrand) * float(self._fmeas[sel].sum())
+        else:
+            X = self.mesh.geometry.x[fv]                                  # (n, d, dim)
+            xq = np.einsum("qa,nad->nqd", self.q_pts, X)
+            env = {"x": [xq[:, :, k] for k in range(xq.shape[2])], "fields": {}}
+            vals = fem.evaluate_numpy(integrand, env)
+            vals = np.broadcast_to(vals, xq.shape[:2])
+            val = float((self._fmeas[sel][:, None] * vals * self.q_w[None, :]).sum())
+        return self.comm.allreduce_sum(val)
+
+    # ---------------------------------------------------------------- backend plumbing
+    def create_backend(self):
+        """Create the libknpemi_hip context for this rank's mesh (fails loudly without a HIP device)."""
+        if self.backend is not None:
+            return self.backend
+        from .backend import Backend
+        self.backend = Backend(self)
+        return self.backend
+
+    def backend_hh_update(self, model):
+        be = self.create_backend()
+        be.hh_update(self.phi_m_prev, self.n, self.m, self.h, float(self.dt.value), float(self.phi_rest.value),
+                     bool(model.use_Rush_Larsen), int(model.time_steps_ODE))
+
+    # class defaults (reference KNPEMIx_problem.py:983-997)
+    mesh_conversion_factor = 1.0
+    fem_order = 1
+    MMS_test = False
+    dirichlet_bcs = False
+    pin_ecs_potential = False
+
+
+def _aslist(v):
+    if isinstance(v, (list, tuple, range)):
+        return list(v)
+    return [v]
+
+
+class ProblemKNPEMI(MixedDimensionalProblem):
+
+    def init(self):
+        pass
+
+    # ---- spaces & restrictions (KNPEMIx_problem.py:28-94)
+    def setup_spaces(self):
+        self.print("Setting up function spaces ...")
+        self.num_variables = self.N_ions + 1
+        self.num_variables_total = 2 * self.num_variables
+        self.V = FunctionSpace(self.mesh)
+        self.V_list = [self.V.clone() for _ in range(self.num_variables_total)]
+        self.V_list_ie = [self.V_list[:self.num_variables], self.V_list[self.num_variables:]]
+        self.wh = [[Function(V) for V in self.V_list_ie[0]], [Function(V) for V in self.V_list_ie[1]]]
+        self.u_out_i, self.u_out_e = [], []
+        for idx, ion in enumerate(self.ion_list):
+            self.wh[0][idx].name = f"{ion['name']}_i"
+            self.wh[1][idx].name = f"{ion['name']}_e"
+            self.u_out_i.append(self.wh[0][idx])
+            self.u_out_e.append(self.wh[1][idx])
+        self.wh[0][self.N_ions].name = "phi_i"
+        self.wh[1][self.N_ions].name = "phi_e"
+        self.u_out_i.append(self.wh[0][self.N_ions])
+        self.u_out_e.append(self.wh[1][self.N_ions])
+        # restricted dofs = vertices of intra / extra cells
+        lm = self.local_mesh
+        in_i = np.zeros(lm.coords.shape[0], dtype=bool)
+        in_e = np.zeros(lm.coords.shape[0], dtype=bool)
+        in_i[lm.cells[self.cell_side == 0].ravel()] = True
+        in_e[lm.cells[self.cell_side == 1].ravel()] = True
+        self.dofs_intra = np.nonzero(in_i)[0].astype(np.int32)
+        self.dofs_extra = np.nonzero(in_e)[0].astype(np.int32)
+
+    def setup_boundary_conditions(self):
+        self.print("Setting up boundary conditions ...")
+        self.bcs = []          # pure Neumann (reference default, KNPEMIx_problem.py:104,198)
+
+    def setup_source_terms(self):
+        raise NotImplementedError
+
+    # ---- initial conditions (KNPEMIx_problem.py:326-353, 386-452)
+    def set_initial_conditions(self):
+        self.print("Setting initial conditions from input file ...")
+        ic = self.initial_conditions
+        if not self.glia_flag:
+            self.phi_m_init.value = ic["phi_m"] if "phi_m" in ic else ic["phi_m_n"]
+            self.Na_i_init.value = ic["Na_i"] if "Na_i" in ic else ic["Na_i_n"]
+            self.Na_e_init.value = ic["Na_e"]
+            self.K_i_init.value = ic["K_i"] if "K_i" in ic else ic["K_i_n"]
+            self.K_e_init.value = ic["K_e"]
+            self.Cl_i_init.value = ic["Cl_i"] if "Cl_i" in ic else ic["Cl_i_n"]
+            self.Cl_e_init.value = ic["Cl_e"]
+        else:
+            self.phi_m_n_init.value = ic["phi_m_n"]; self.phi_m_g_init.value = ic["phi_m_g"]
+            self.Na_i_n_init.value = ic["Na_i_n"]; self.Na_i_g_init.value = ic["Na_i_g"]
+            self.Na_e_init.value = ic["Na_e"]
+            self.K_i_n_init.value = ic["K_i_n"]; self.K_i_g_init.value = ic["K_i_g"]
+            self.K_e_init.value = ic["K_e"]
+            self.Cl_i_n_init.value = ic["Cl_i_n"]; self.Cl_i_g_init.value = ic["Cl_i_g"]
+            self.Cl_e_init.value = ic["Cl_e"]
+        self.n_init.value = ic["n"]; self.m_init.value = ic["m"]; self.h_init.value = ic["h"]
+
+        self.phi_m_prev = Function(self.V, "phi_m")
+        ui_p, ue_p = self.wh[0], self.wh[1]
+        if not self.glia_flag:
+            self.phi_m_prev.x.array[:] = self.phi_m_init.value
+            self.print(f"Initial membrane potential: {self.phi_m_init.value}")
+            ui_p[self.N_ions].x.array[:] = self.phi_m_init.value
+            ue_p[self.N_ions].x.array[:] = 0.0
+        else:
+            dev = self.mesh.device
+            self.neuron_dofs = torch.as_tensor(np.unique(self.local_mesh.cells[self.neuron_cells].ravel()), device=dev, dtype=torch.long)
+            self.glia_dofs = torch.as_tensor(np.unique(self.local_mesh.cells[self.glia_cells].ravel()), device=dev, dtype=torch.long)
+            self.phi_m_prev.x.array[self.neuron_dofs] = self.phi_m_n_init.value
+            self.phi_m_prev.x.array[self.glia_dofs] = self.phi_m_g_init.value
+            ui_p[self.N_ions].x.array[self.neuron_dofs] = self.phi_m_n_init.value
+            ui_p[self.N_ions].x.array[self.glia_dofs] = self.phi_m_g_init.value
+            ue_p[self.N_ions].x.array[:] = 0.0
+        for idx, ion in enumerate(self.ion_list):
+            if self.glia_flag:
+                ui_p[idx].x.array[self.neuron_dofs] = ion["ki_init_n"].value
+                ui_p[idx].x.array[self.glia_dofs] = ion["ki_init_g"].value
+                ue_p[idx].x.array[:] = ion["ke_init"].value
+            else:
+                ui_p[idx].x.array[:] = ion["ki_init"].value
+                ue_p[idx].x.array[:] = ion["ke_init"].value
+                self.print(f"Initial condition for {ion['name']}_i set to {ion['ki_init'].value}")
+                self.print(f"Initial condition for {ion['name']}_e set to {ion['ke_init'].value}")
+        self.print("Initial conditions set.")
+
+    # ---- "variational form": compile the membrane currents (KNPEMIx_problem.py:504-555)
+    def setup_variational_form(self):
+        from .ionic_models import HodgkinHuxley
+        self.print("Setting up variational form ...")
+        psi = self.psi
+        ui_p, ue_p = self.wh[0], self.wh[1]
+        for idx, ion in enumerate(self.ion_list):
+            ion["E"] = (psi / ion["z"]) * fem.ln(ue_p[idx] / ui_p[idx])                # :516
+            ion["I_ch"] = dict.fromkeys(self.gamma_tags, fem.ZeroBaseForm(None))
+        I_ch = dict.fromkeys(self.gamma_tags, fem.ZeroBaseForm(None))
+        for idx, ion in enumerate(self.ion_list):
+            for model in self.ionic_models:
+                for gamma_tag in model.tags:
+                    I_ch_k_ = model._eval(idx)
+                    if (gamma_tag in self.stimulus_tags and ion["name"] == "Na" and isinstance(model, HodgkinHuxley)):
+                        if self.stimulus_region:
+                            if not self.multiple_stimulus_directions:
+                                stim = model._add_stimulus(idx, step=True, range=self.stimulus_region_range, dir=self.stimulus_region_direction)
+                            else:
+                                stim = model._add_stimulus(idx, step=True, range=self.stimulus_region_range, dir=self.stimulus_region_directions)
+                        else:
+                            stim = model._add_stimulus(idx, step=True)
+                        I_ch_k_ = I_ch_k_ + stim
+                        self.print(f"Stimulus added on membrane with tag {gamma_tag}.")
+                        self.stim_ufl_expr = stim
+                    ion["I_ch"][gamma_tag] = ion["I_ch"][gamma_tag] + I_ch_k_
+                    I_ch[gamma_tag] = I_ch[gamma_tag] + I_ch_k_
+        # one bytecode program per membrane tag
+        roles = {}
+        for j in range(self.N_ions):
+            roles[id(ui_p[j])] = ("KI", j)
+            roles[id(ue_p[j])] = ("KE", j)
+        roles[id(self.phi_m_prev)] = ("PHIM", 0)
+        self.aux_functions = []
+        self.programs = {}
+        for k, tag in enumerate(self.gamma_tags):
+            outs = [self.ion_list[j]["I_ch"][tag] for j in range(self.N_ions)]
+            self.programs[k] = fem.compile_program(outs, roles, self.aux_functions)
+        self.a = "hard-wired in knp_kernels.hip (k_assemble_pairs, k_gamma_facets, k_gamma_pairs)"
+        self.L = "hard-wired in knp_kernels.hip (k_rhs, k_gamma_facets) + membrane programs"
+        if self.backend is not None:
+            self.backend.upload_programs()
+
+    def setup_preconditioner(self, use_block_jacobi: bool):
+        self.print("Setting up preconditioner ...")
+        if not use_block_jacobi:
+            raise NotImplementedError("Only the block-Jacobi preconditioner form (KNPEMIx_problem.py:717-719) is implemented.")
+        self.P = "hard-wired in knp_kernels.hip (k_assemble_pairs<true>, k_gamma_pairs<true>)"
+
+    def print_conservation(self):
+        be = self.create_backend()
+        tot = be.total_ion_amounts()
+        self.print(f"Time {self.t.value*1e3:.2f} ms")
+        for name, v in zip(("Na+", "K+ ", "Cl-"), tot):
+            self.print(f"Total {name} concentration: {v:.2e} mol")
+
+    def print_errors(self):
+        raise NotImplementedError("MMS path not available (SURVEY 8f-1).")
+
+    # ---- constants (KNPEMIx_problem.py:909-981)
+    def setup_constants(self):
+        m = self.mesh
+        self.C_M = Constant(m, self.C_M_value)
+        self.T = Constant(m, self.T_value)
+        self.F = Constant(m, self.F_value)
+        self.R = Constant(m, self.R_value)
+        self.psi = Constant(m, self.psi_value)
+        self.g_Na_bar = Constant(m, self.g_Na_bar_val)
+        self.g_K_bar = Constant(m, self.g_K_bar_val)
+        self.g_Na_leak = Constant(m, self.g_Na_leak_val)
+        self.g_Na_leak_g = Constant(m, self.g_Na_leak_g_val)
+        self.g_K_leak = Constant(m, self.g_K_leak_val)
+        self.g_K_leak_g = Constant(m, self.g_K_leak_g_val)
+        self.g_Cl_leak = Constant(m, self.g_Cl_leak_val)
+        self.g_Cl_leak_g = Constant(m, self.g_Cl_leak_g_val)
+        self.g_syn_bar = Constant(m, self.g_syn_bar_val)
+        self.a_syn = Constant(m, self.a_syn_val)
+        self.T_stim = Constant(m, self.T_stim_val)
+        self.D_Na = Constant(m, 1.33e-9)
+        self.D_K = Constant(m, 1.96e-9)
+        self.D_Cl = Constant(m, 2.03e-9)
+        self.phi_rest = Constant(m, -0.065)
+        self.rho_pump = Constant(m, 1.115e-6)
+        self.P_Nai = Constant(m, 10)
+        self.P_Ke = Constant(m, 1.5)
+        self.k_dec = Constant(m, 2.9e-8)
+        self.phi_m_init = Constant(m, -0.070)
+        self.Na_i_init = Constant(m, 10); self.Na_e_init = Constant(m, 145)
+        self.K_i_init = Constant(m, 130); self.K_e_init = Constant(m, 3)
+        self.Cl_i_init = Constant(m, 5); self.Cl_e_init = Constant(m, 134)
+        self.phi_m_n_init = Constant(m, self.phi_m_init.value)
+        self.phi_m_g_init = Constant(m, -0.085)
+        self.Na_i_n_init = Constant(m, self.Na_i_init.value)
+        self.K_i_n_init = Constant(m, self.K_i_init.value)
+        self.Cl_i_n_init = Constant(m, self.Cl_i_init.value)
+        self.Na_i_g_init = Constant(m, 15)
+        self.K_i_g_init = Constant(m, 100)
+        self.Cl_i_g_init = Constant(m, 5)
+        self.n_init = Constant(m, 0.24458654944007155)
+        self.m_init = Constant(m, 0.028905534475191896)
+        self.h_init = Constant(m, 0.7540796658225248)
+        self.Na_e_f = Constant(m, 0.0); self.Na_i_f = Constant(m, 0.0)
+        self.K_e_f = Constant(m, 0.0); self.K_i_f = Constant(m, 0.0)
+        self.Cl_e_f = Constant(m, 0.0); self.Cl_i_f = Constant(m, 0.0)
+        self.Na = {"name": "Na", "g_leak": self.g_Na_leak, "g_leak_g": self.g_Na_leak_g, "Di": self.D_Na, "De": self.D_Na,
+                   "ki_init": self.Na_i_init, "ke_init": self.Na_e_init, "ki_init_n": self.Na_i_n_init,
+                   "ki_init_g": self.Na_i_g_init, "z": Constant(m, 1.0), "f_e": self.Na_e_f, "f_i": self.Na_i_f}
+        self.K = {"name": "K", "g_leak": self.g_K_leak, "g_leak_g": self.g_K_leak_g, "Di": self.D_K, "De": self.D_K,
+                  "ki_init": self.K_i_init, "ke_init": self.K_e_init, "ki_init_n": self.K_i_n_init,
+                  "ki_init_g": self.K_i_g_init, "z": Constant(m, 1.0), "f_e": self.K_e_f, "f_i": self.K_i_f}
+        self.Cl = {"name": "Cl", "g_leak": self.g_Cl_leak, "g_leak_g": self.g_Cl_leak_g, "Di": self.D_Cl, "De": self.D_Cl,
+                   "ki_init": self.Cl_i_init, "ke_init": self.Cl_e_init, "ki_init_n": self.Cl_i_n_init,
+                   "ki_init_g": self.Cl_i_g_init, "z": Constant(m, -1.0), "f_e": self.Cl_e_f, "f_i": self.Cl_i_f}
+        self.ion_list = [self.Na, self.K, self.Cl]
+        self.N_ions = len(self.ion_list)

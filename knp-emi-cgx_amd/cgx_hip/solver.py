@@ -1,0 +1,335 @@
+"""``SolverKNPEMI``: the reference's time-loop / linear-solver surface on top of libknpemi_hip.
+
+Mirrors reference src/CGx/KNPEMI/KNPEMIx_solver.py: same constructor, same class-level defaults
+(:25-51), same per-step order (:365-468): advance t -> HH gating update -> assemble A, b ->
+(step 1) null space -> solve -> unpack -> phi_m_prev = phi_i - phi_e; same timing lists
+(``assembly_time``, ``solve_time``, ``iterations``) and ``print_info`` fields (:504-548).
+
+Linear solver mapping (reference :211-214, 269-280):
+  ksp_type gmres           -> knp_gmres_solve: GMRES(30), left preconditioning, classical
+                              Gram-Schmidt, preconditioned norm, non-zero initial guess
+  pc_type  hypre           -> smoothed-aggregation AMG V-cycle on the block-diagonal P (cgx_hip/amg.py
+                              + HIP V-cycle), the native stand-in for BoomerAMG
+  pc_type  bjacobi|vbjacobi-> per-vertex 4x4 / 8x8 block Jacobi of A (HIP)
+  pc_type  none            -> unpreconditioned
+  direct: True             -> MUMPS has no native counterpart; emulated by GMRES+AMG driven to
+                              rtol 1e-13 with the l2 gauge of the iterative path (the gauge constant
+                              therefore differs from MUMPS's, see tests/test_oracle_pins.py).
+Unlike the reference (which never checks ``ksp.getConvergedReason()``), non-convergence is recorded
+in ``self.reasons`` and raises when ``strict`` is set.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import torch
+
+from . import _lib, amg
+from .ionic_models import HodgkinHuxley
+from .problem import ProblemKNPEMI
+
+
+class _KSPInfo:
+    """What callers read off ``solver.ksp`` in the reference."""
+
+    def __init__(self):
+        self.its = 0
+        self.reason = 0
+        self.rnorm = 0.0
+
+    def getIterationNumber(self):
+        return self.its
+
+    def getConvergedReason(self):
+        return self.reason
+
+    def getResidualNorm(self):
+        return self.rnorm
+
+
+class SolverKNPEMI:
+    ksp_type = "gmres"
+    pc_type = "hypre"
+    ksp_rtol = 1e-8
+    ksp_max_it = 5000
+    use_P_mat = True
+    reassemble_P = False
+    reassemble_N = 1
+    verbose = False
+    use_block_Jacobi = True
+    nonzero_init_guess = True
+    norm_type = "preconditioned"
+    max_amg_iter = 1
+    strong_threshold = 0.5
+    save_interval = 20
+    tot_its = 0.0
+    tot_assembly_time = 0.0
+    tot_solver_time = 0.0
+    gmres_restart = 30
+    strict = False
+    # native AMG parameters
+    amg_theta = 0.08
+    amg_cheby_degree = 2
+    amg_pre = 1
+    amg_post = 1
+
+    def __init__(self, problem: ProblemKNPEMI, solver_config: dict):
+        self.problem = problem
+        self.comm = problem.comm
+        self.time_steps = problem.time_steps
+        out = solver_config.get("output", {}) if isinstance(solver_config.get("output", {}), dict) else {}
+        self.save_xdmfs = out.get("save_xdmf", False)
+        self.save_pngs = out.get("save_pngs", False)
+        self.save_cpoints = out.get("save_cpoints", False)
+        self.save_dat = out.get("save_dat", False)
+        self.save_mat = out.get("save_mat", False)
+        if "save_interval" in out:
+            self.save_interval = out["save_interval"]
+        if self.save_xdmfs or self.save_pngs or self.save_cpoints:
+            raise NotImplementedError("XDMF / PNG / checkpoint output is outside the native hot path (SURVEY 8f-4); "
+                                      "set save_xdmf/save_pngs/save_cpoints to False.")
+        self.out_file_prefix = problem.output_dir
+        self.direct_solver = bool(solver_config["direct"])
+        self.view_input = solver_config.get("view_ksp", False)
+        if "ksp_settings" in solver_config:
+            ks = solver_config["ksp_settings"]
+            if "ksp_type" in ks: self.ksp_type = ks["ksp_type"]
+            if "pc_type" in ks: self.pc_type = ks["pc_type"]
+            if "ksp_rtol" in ks: self.ksp_rtol = float(ks["ksp_rtol"])
+            if "norm_type" in ks: self.norm_type = ks["norm_type"]
+            if "strong_threshold" in ks: self.strong_threshold = float(ks["strong_threshold"])
+            if "reassemble_P" in ks: self.reassemble_P = bool(ks["reassemble_P"])
+            if "non_zero_init_guess" in ks: self.nonzero_init_guess = bool(ks["non_zero_init_guess"])
+            if "ksp_max_it" in ks: self.ksp_max_it = int(ks["ksp_max_it"])
+            if "gmres_restart" in ks: self.gmres_restart = int(ks["gmres_restart"])
+            if "strict" in ks: self.strict = bool(ks["strict"])
+            for k in ("amg_theta", "amg_cheby_degree", "amg_pre", "amg_post"):
+                if k in ks: setattr(self, k, type(getattr(self, k))(ks[k]))
+        if self.ksp_type != "gmres":
+            raise NotImplementedError(f"ksp_type '{self.ksp_type}': only 'gmres' is implemented natively.")
+        if self.pc_type not in ("hypre", "amg", "bjacobi", "vbjacobi", "none"):
+            raise NotImplementedError(f"pc_type '{self.pc_type}' has no native counterpart (hypre|amg|bjacobi|vbjacobi|none).")
+        if self.norm_type != "preconditioned":
+            raise NotImplementedError("only norm_type 'preconditioned' is implemented (reference default).")
+        if self.save_mat:
+            self.time_steps = 1
+        self.ksp = _KSPInfo()
+        self.setup_time = 0.0
+        self.reasons = []
+        self.ode_time = []
+
+    def print(self, *a, **k):
+        self.problem.print(*a, **k)
+
+    # ---- reference :104-116
+    def assemble(self):
+        self.print("Assembling linear system ...")
+        be = self.backend
+        be.assemble_matrix()
+        be.assemble_rhs()
+
+    # ---- reference :118-135
+    def assemble_preconditioner(self):
+        self.print("Assembling preconditioner ...")
+        be = self.backend
+        be.assemble_precond()
+        if self._pc_kind == _lib.PC_AMG:
+            tic = time.perf_counter()
+            P = be.precond_csr()
+            P = P[:, :be.n_dof_owned].tocsr()          # per-rank block (block-Jacobi across GPUs)
+            self.hierarchy = amg.build_hierarchy(P, theta=self.amg_theta)
+            amg.upload(be.lib, be.ctx, be.check, self.hierarchy, self.amg_pre, self.amg_post, self.amg_cheby_degree)
+            self.amg_setup_time = time.perf_counter() - tic
+            self.print(f"AMG hierarchy: {self.hierarchy.describe()} (host setup {self.amg_setup_time:0.3f} s)")
+        self.P_ = "device CSR (see Backend.precond_csr)"
+
+    def reassemble_preconditioner(self):
+        self.print("Re-assembling preconditioner ...")
+        self.assemble_preconditioner()
+        self.backend.pc_setup(self._pc_kind)
+
+    # ---- reference :152-295
+    def setup_solver(self):
+        p = self.problem
+        self.backend = p.create_backend()
+        be = self.backend
+        self.A = be                                   # matrix handle: be.csr(), be.spmv()
+        self.b = be.b
+        self.x = be.x
+        if self.direct_solver:
+            self.print("Direct solver requested: emulated natively by GMRES+AMG at rtol 1e-13 (no MUMPS on the GPU).")
+            self._pc_kind = _lib.PC_AMG
+            self._rtol = 1e-13
+        else:
+            self.print("Setting up iterative solver ...")
+            self._pc_kind = {"hypre": _lib.PC_AMG, "amg": _lib.PC_AMG, "bjacobi": _lib.PC_VBJACOBI,
+                             "vbjacobi": _lib.PC_VBJACOBI, "none": _lib.PC_NONE}[self.pc_type]
+            self._rtol = self.ksp_rtol
+        # initial conditions as initial guess (reference :177-209)
+        for idx, ion in enumerate(p.ion_list):
+            if not p.glia_flag:
+                p.wh[0][idx].x.array[:] = ion["ki_init"].value
+                p.wh[1][idx].x.array[:] = ion["ke_init"].value
+            else:
+                p.wh[0][idx].x.array[p.neuron_dofs] = ion["ki_init_n"].value
+                p.wh[0][idx].x.array[p.glia_dofs] = ion["ki_init_g"].value
+                p.wh[1][idx].x.array[:] = ion["ke_init"].value
+        if not p.glia_flag:
+            p.wh[0][p.N_ions].x.array[:] = p.phi_m_init.value
+            p.wh[1][p.N_ions].x.array[:] = 0.0
+        else:
+            p.wh[0][p.N_ions].x.array[p.neuron_dofs] = p.phi_m_n_init.value
+            p.wh[0][p.N_ions].x.array[p.glia_dofs] = p.phi_m_g_init.value
+            p.wh[1][p.N_ions].x.array[:] = 0.0
+        if self.nonzero_init_guess or self.direct_solver:
+            be.pack()
+        else:
+            be.x.zero_()
+        self.iterations = []
+        self.solve_time = []
+        self.assembly_time = []
+
+    # ---- reference :297-335
+    def create_and_set_nullspace(self):
+        self.print("Creating and setting null space ...")
+        be = self.backend
+        nrm = be.nullspace_test()
+        a_scale = max(1e-300, float(self._matrix_scale()))
+        assert nrm <= 1e-8 * a_scale, f"constant potential is not in the null space of A (||A ns|| = {nrm:.3e})"
+        be.set_nullspace(True)
+        be.project_nullspace(be.b)
+        self.print("Null space set.")
+
+    def _matrix_scale(self):
+        # ||A||_inf-ish scale from a probe SpMV with the all-ones vector (cheap, setup only)
+        be = self.backend
+        ones = torch.ones(be.n_dof_local, dtype=torch.float64, device=be.device)
+        y = torch.empty(be.n_dof_local, dtype=torch.float64, device=be.device)
+        be.spmv(ones, y)
+        return self.comm.allreduce_max(float(y[:be.n_dof_owned].abs().max().item()) if be.n_dof_owned else 0.0) + 1e-300
+
+    def _sync(self):
+        torch.cuda.synchronize()
+
+    # ---- reference :337-501
+    def solve(self):
+        p = self.problem
+        t, dt = p.t, p.dt
+        setup_timer = 0.0
+        tic = time.perf_counter()
+        self.setup_solver()
+        be = self.backend
+        self._sync()
+        setup_timer += self.comm.allreduce_max(time.perf_counter() - tic)
+        if self.use_P_mat and self._pc_kind == _lib.PC_AMG:
+            tic = time.perf_counter()
+            p.setup_preconditioner(self.use_block_Jacobi)
+            self.assemble_preconditioner()
+            self._sync()
+            setup_timer += self.comm.allreduce_max(time.perf_counter() - tic)
+
+        for i in range(1, self.time_steps + 1):
+            p.t.value += float(dt.value)
+            self.print("\nTime step ", i)
+            self.print("t (ms) = ", 1000 * float(t.value))
+            if i == 1:
+                tic = time.perf_counter()
+                be.pc_setup(self._pc_kind)            # ksp.setOperators + ksp.setUp
+                self._sync()
+                setup_timer += self.comm.allreduce_max(time.perf_counter() - tic)
+
+            if p.gating_variables:
+                tic = time.perf_counter()
+                for model in p.ionic_models:
+                    if isinstance(model, HodgkinHuxley):
+                        model.update_t_mod()
+                        model.update_gating_variables()
+                self._sync()
+                self.ode_time.append(self.comm.allreduce_max(time.perf_counter() - tic))
+
+            tic = time.perf_counter()
+            self.assemble()
+            if i > 1 and self.reassemble_P and (i % self.reassemble_N == 0) and self.use_P_mat and self._pc_kind == _lib.PC_AMG:
+                self.reassemble_preconditioner()
+            self._sync()
+            max_assembly_time = self.comm.allreduce_max(time.perf_counter() - tic)
+            self.tot_assembly_time += max_assembly_time
+            self.assembly_time.append(max_assembly_time)
+            self.print(f"Time dependent assembly in {max_assembly_time:0.4f} seconds")
+
+            if i == 1 and not p.dirichlet_bcs and not p.pin_ecs_potential:
+                tic = time.perf_counter()
+                self.create_and_set_nullspace()
+                self._sync()
+                setup_timer += self.comm.allreduce_max(time.perf_counter() - tic)
+
+            if self.save_mat:
+                A = be.csr().tocoo()
+                np.save(self.out_file_prefix + "Amat", np.c_[A.row, A.col, A.data])
+                return
+
+            tic = time.perf_counter()
+            its, rnorm, reason = be.gmres(self._rtol, 1e-50, self.ksp_max_it, self.gmres_restart)
+            self.ksp.its, self.ksp.rnorm, self.ksp.reason = its, rnorm, reason
+            self.tot_its += its
+            self._sync()
+            max_solver_time = self.comm.allreduce_max(time.perf_counter() - tic)
+            self.tot_solver_time += max_solver_time
+            self.solve_time.append(max_solver_time)
+            self.print(f"Solved in {max_solver_time:0.4f} seconds ({its} its, {_lib.REASONS.get(reason, reason)}, |r| = {rnorm:.3e})")
+            self.iterations.append(its)
+            self.reasons.append(reason)
+            if reason < 0 and self.strict:
+                raise RuntimeError(f"GMRES did not converge at step {i}: {_lib.REASONS.get(reason, reason)}")
+
+            be.unpack()                                # x -> wh, phi_m_prev = phi_i - phi_e (reference :452-468)
+
+            if i == self.time_steps:
+                self.setup_time = setup_timer
+                self.print("\nTotal setup time:", setup_timer)
+                self.print("Total assembly time:", sum(self.assembly_time))
+                self.print("Total solve time:", sum(self.solve_time))
+                self.print_info()
+                if self.save_dat:
+                    self.export_data()
+
+    def potential_norms(self):
+        """L2 norms of phi_i over Omega_i and phi_e over Omega_e (reference main.py:70-84)."""
+        a, b = self.backend.l2_norms_sq()
+        return float(np.sqrt(a)), float(np.sqrt(b))
+
+    def export_data(self):
+        """Timing / iteration arrays with the reference's file names (KNPEMIx_solver.py:862-866)."""
+        if self.comm.rank == 0:
+            np.save(self.out_file_prefix + "assembly_time.npy", np.array(self.assembly_time))
+            np.save(self.out_file_prefix + "solve_time.npy", np.array(self.solve_time))
+            np.save(self.out_file_prefix + "iterations.npy", np.array(self.iterations))
+
+    # ---- reference :504-548
+    def print_info(self):
+        p = self.problem
+        be = self.backend
+        pr = self.print
+        pr("\n#------------ PROBLEM -------------#\n")
+        pr("MPI Size = ", self.comm.size)
+        pr("Input mesh = ", p.mesh_description)
+        pr("Global # mesh cells = ", p.local_mesh.n_cells_global)
+        pr("System size (global # dofs) = ", be.n_dof_global)
+        pr("FEM order = ", p.fem_order)
+        pr("# Time steps = ", self.time_steps)
+        pr("dt = ", float(p.dt.value))
+        pr("Using Dirichlet BCs." if p.dirichlet_bcs else "Using Neumann BCs.")
+        pr("\n#------------ SOLVER -------------#\n")
+        if self.direct_solver:
+            pr("Direct solve emulated by GMRES+AMG (rtol 1e-13).")
+        else:
+            pr("Solver type: [" + self.ksp_type + "+" + self.pc_type + "]")
+            pr(f"Tolerance: {self.ksp_rtol:.2e}")
+            pr(f"Norm type: {self.norm_type}")
+            pr(f"None-zero initial guess: {self.nonzero_init_guess}")
+            if self.use_P_mat: pr("Preconditioner matrix P enabled.")
+            if self.use_block_Jacobi: pr("Using block-Jacobi preconditioner form.")
+            if self.reassemble_P: pr(f"Re-assembling preconditioner every {self.reassemble_N} timesteps.")
+        if self.iterations:
+            pr("Average iterations: " + str(sum(self.iterations) / len(self.iterations)))

@@ -1,0 +1,153 @@
+// Internal structures of libknpemi_hip.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "knpemi_hip.h"
+
+#define KNP_NPROF 5
+
+// ---- host-side result of the graph builder (knp_setup.cpp) -------------------------------
+struct KnpHostGraph {
+    int dim = 0, nv1 = 0;
+    int n_v = 0, n_v_owned = 0, n_c = 0, n_c_owned = 0, n_g = 0, n_q = 0;
+    int n_nodes = 0, n_nodes_owned = 0;
+    std::vector<int32_t> node_i, node_e;          // [n_v]
+    std::vector<int32_t> node_vertex;             // [n_nodes]
+    std::vector<uint8_t> node_side;               // [n_nodes]
+    // same-side node graph (owned rows)
+    std::vector<int32_t> pair_ptr;                // [n_nodes_owned+1]
+    std::vector<int32_t> pair_col;                // [n_pairs] node ids (sorted per row)
+    std::vector<int32_t> pair_row;                // [n_pairs]
+    std::vector<double> pair_M, pair_K;           // [n_pairs]
+    std::vector<int32_t> contrib_ptr;             // [n_pairs+1]
+    std::vector<int32_t> contrib_cell;            // [n_contrib]
+    std::vector<double> contrib_k;                // [n_contrib]
+    // membrane graph
+    std::vector<int32_t> fv;                      // [n_g*dim] facet vertices
+    std::vector<double> fmeas;                    // [n_g]
+    int n_gv = 0;                                 // owned membrane vertices
+    std::vector<int32_t> gv_vertex, gv_node_i, gv_node_e;  // [n_gv]
+    std::vector<int32_t> node_gv;                 // [n_nodes_owned] index of the membrane vertex or -1
+    std::vector<int32_t> gptr;                    // [n_gv+1]
+    std::vector<int32_t> gcol;                    // [n_gp] membrane-vertex neighbours as VERTEX ids
+    std::vector<int32_t> grow;                    // [n_gp] owning membrane-vertex index
+    std::vector<int32_t> gq_i, gq_e;              // [n_gp] slot of the neighbour in the same-side rows
+    std::vector<int32_t> gx_i, gx_e;              // [n_gp] node ids of the cross columns (extra node for the intra row, ...)
+    std::vector<int32_t> gdiag;                   // [n_gv] slot with gcol == own vertex
+    std::vector<int32_t> gcptr;                   // [n_gp+1]
+    std::vector<int32_t> gc_facet;                // [n_gc]
+    std::vector<int32_t> gc_lab;                  // [n_gc] la*4+lb
+    // CSR pattern of A
+    std::vector<int32_t> rowptr;                  // [4*n_nodes_owned+1]
+    std::vector<int32_t> colind;                  // [nnz]
+    std::string error;
+};
+
+int knp_build_graph(const knp_mesh_desc* m, KnpHostGraph& g);
+
+// ---- device-side program ------------------------------------------------------------------
+struct KnpProgram {
+    int n_instr = 0, n_consts = 0;
+    int32_t* d_code = nullptr;
+    double* d_consts = nullptr;
+};
+
+struct KnpAmgLevel {
+    int n = 0, n_coarse = 0;
+    int32_t *A_rp = nullptr, *A_ci = nullptr;
+    double* A_v = nullptr;
+    double* inv_diag = nullptr;
+    double lambda_max = 1.0;
+    int32_t *P_rp = nullptr, *P_ci = nullptr;
+    double* P_v = nullptr;
+    int32_t *R_rp = nullptr, *R_ci = nullptr;
+    double* R_v = nullptr;
+    double *x = nullptr, *b = nullptr, *r = nullptr, *d = nullptr;  // work vectors
+    int A_lanes = 8, P_lanes = 4, R_lanes = 8;
+};
+
+struct knp_ctx {
+    std::string err;
+    hipStream_t stream = nullptr;
+    int device = 0;
+    KnpHostGraph g;  // host copy kept (pattern export, diagnostics)
+    // params
+    double dt = 0, F = 1, C_M = 1, psi = 1;
+    int n_ions = 3;
+    double z[KNP_MAX_IONS] = {1, 1, -1}, Di[KNP_MAX_IONS] = {1, 1, 1}, De[KNP_MAX_IONS] = {1, 1, 1};
+    // sizes
+    int64_t nnz = 0, n_pairs = 0, n_contrib = 0, n_gp = 0, n_gc = 0;
+    int n_dof_owned = 0, n_dof_local = 0;
+    // device mesh / graph
+    int32_t* d_cells = nullptr;
+    uint8_t* d_cell_side = nullptr;
+    double* d_coords = nullptr;
+    int32_t* d_node_vertex = nullptr;
+    uint8_t* d_node_side = nullptr;
+    int32_t *d_node_i = nullptr, *d_node_e = nullptr;
+    int32_t *d_pair_ptr = nullptr, *d_pair_col = nullptr, *d_pair_row = nullptr;
+    double *d_pair_M = nullptr, *d_pair_K = nullptr;
+    int32_t *d_contrib_ptr = nullptr, *d_contrib_cell = nullptr;
+    double* d_contrib_k = nullptr;
+    int32_t* d_fv = nullptr;
+    double* d_fmeas = nullptr;
+    int32_t* d_gamma_prog = nullptr;
+    double *d_qp = nullptr, *d_qw = nullptr;
+    int32_t *d_gv_vertex = nullptr, *d_gv_node_i = nullptr, *d_gv_node_e = nullptr, *d_node_gv = nullptr;
+    int32_t *d_gptr = nullptr, *d_gcol = nullptr, *d_grow = nullptr, *d_gq_i = nullptr, *d_gq_e = nullptr,
+            *d_gdiag = nullptr;
+    int32_t *d_gcptr = nullptr, *d_gc_facet = nullptr, *d_gc_lab = nullptr;
+    // CSR of A and P
+    int32_t *d_rowptr = nullptr, *d_colind = nullptr;
+    double* d_vals = nullptr;
+    int32_t *d_p_rowptr = nullptr, *d_p_colind = nullptr;
+    double* d_p_vals = nullptr;
+    bool have_A = false, have_P = false;
+    // work arrays
+    double* d_cbar = nullptr;   // [3*n_c]
+    double* d_fmat = nullptr;   // [6*npk*n_g]
+    double* d_fvec = nullptr;   // [7*dim*n_g]
+    // programs
+    std::vector<KnpProgram> progs;
+    int32_t** d_prog_code = nullptr;   // device table of pointers
+    double** d_prog_consts = nullptr;
+    int32_t* d_prog_len = nullptr;
+    bool progs_dirty = true;
+    int max_prog = -1;
+    // sources
+    const double* src_i[KNP_MAX_IONS] = {nullptr, nullptr, nullptr};
+    const double* src_e[KNP_MAX_IONS] = {nullptr, nullptr, nullptr};
+    bool have_sources = false;
+    // preconditioner
+    int pc_kind = KNP_PC_NONE;
+    double* d_vbj = nullptr;  // [n_nodes_owned*16] compact vertex blocks
+    int amg_levels = 0, amg_pre = 1, amg_post = 1, amg_cheby = 2;
+    KnpAmgLevel amg[KNP_MAX_AMG_LEVELS];
+    int amg_nc = 0;
+    double* d_amg_cinv = nullptr;
+    // null space
+    int ns_on = 0;
+    // GMRES workspace
+    int gm_restart = 0;
+    double* d_V = nullptr;       // [(restart+1)*n_dof_local]
+    double *d_w = nullptr, *d_t = nullptr;  // [n_dof_local]
+    double* d_partial = nullptr; // reduction scratch
+    double* d_red = nullptr;     // [64] reduced values
+    double* h_red = nullptr;     // pinned host mirror
+    double* d_y = nullptr;       // [restart+1]
+    int n_red_blocks = 0;
+    // comm
+    knp_halo_fn halo = nullptr;
+    knp_allreduce_fn allreduce = nullptr;
+    void* comm_user = nullptr;
+    // profiling
+    int prof_on = 0;
+    struct ProfRec { hipEvent_t a, b; int cls; };
+    std::vector<ProfRec> prof_recs;
+    double prof_ms[KNP_NPROF] = {0, 0, 0, 0, 0};
+    int64_t prof_n[KNP_NPROF] = {0, 0, 0, 0, 0};
+};

@@ -1,0 +1,1823 @@
+// libknpemi_hip -- HIP kernels (gfx950, wave64, fp64) and the C-ABI for the KNP-EMI
+// assemble-and-solve hot path.  Everything here is HBM-bandwidth bound: no MFMA.
+//
+//   K0  k_cell_means            per-cell means of the previous concentrations (feeds K[c] blocks)
+//   K1  k_assemble_pairs        gather-assembly of all volume blocks of A (or P) into CSR, one
+//                               thread per same-side node pair, atomic-free and deterministic
+//   K2  k_gamma_facets          membrane facet quadrature (rational alpha weights, mechanism programs)
+//   K2b k_gamma_pairs           gather of facet matrices into the CSR coupling entries
+//   K3  k_rhs                   mass * k_prev + membrane vectors -> b
+//   K4  k_spmv                  CSR SpMV, sub-wave per row, shuffle reduction
+//   K5  k_multi_dot / k_update_norm   classical Gram-Schmidt (fused multi-dot, fused update + norm)
+//   K6  k_scale, k_lincomb
+//   K7  k_vbj_extract / k_vbj_apply   per-vertex 4x4 / 8x8 block-Jacobi (Schur form, no stored inverse)
+//   K8  k_phi_sum / k_phi_sub   null-space (gauge) projection
+//   K9  k_hh_update             Hodgkin-Huxley gating (Rush-Larsen collapsed analytically / forward Euler)
+//   K10 k_pack / k_unpack       solution vector <-> nodal fields, phi_m = phi_i - phi_e
+//   AMG k_cheby_step, k_dense_matvec  V-cycle pieces (level SpMVs reuse K4)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "knp_internal.hpp"
+
+#define HIPCHK(call)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                  \
+            return KNP_E_HIP;                                                              \
+        }                                                                                  \
+    } while (0)
+#define KCHK(expr)                         \
+    do {                                   \
+        int rc_ = (expr);                  \
+        if (rc_ != KNP_OK) return rc_;     \
+    } while (0)
+#define CHECK_CTX(ctx) \
+    if (!(ctx)) return KNP_E_ARG
+
+static constexpr int NT = 256;          // threads per block everywhere
+static constexpr int RED_BLOCKS = 1024; // reduction partial blocks (4 per CU on 256 CUs)
+static constexpr int RED_SLOTS = 64;    // reduced-value slots
+
+struct DevParams {
+    double dt, F, C_M, psi;
+    double z[3], Di[3], De[3];
+};
+struct FieldPtrs {
+    const double* ki[3];
+    const double* ke[3];
+    const double* phim;
+    const double* aux[KNP_MAX_AUX];
+};
+
+static inline int nblocks(int64_t n, int per = NT) { return (int)std::max<int64_t>(1, (n + per - 1) / per); }
+
+// ------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// sum over the block; result valid in thread 0
+__device__ __forceinline__ double block_sum(double v, double* sm) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) sm[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x < (NT >> 6)) r = sm[threadIdx.x];
+    if (w == 0) r = wave_sum(r);
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// K0: cell means
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(NT) k_cell_means(int n_c, int nv1, const int32_t* __restrict__ cells,
+                                                   const uint8_t* __restrict__ side, FieldPtrs f,
+                                                   double* __restrict__ cbar) {
+    int c = blockIdx.x * NT + threadIdx.x;
+    if (c >= n_c) return;
+    const int s = side[c];
+    const double inv = 1.0 / nv1;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double* k = s ? f.ke[j] : f.ki[j];
+        double acc = 0.0;
+        for (int a = 0; a < nv1; ++a) acc += k[cells[(size_t)c * nv1 + a]];
+        cbar[(size_t)j * n_c + c] = acc * inv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: volume blocks, one thread per node pair
+// ------------------------------------------------------------------------------------------
+template <bool PRECOND>
+__global__ void __launch_bounds__(NT)
+k_assemble_pairs(int64_t n_pairs, int n_c, DevParams P, const int32_t* __restrict__ pair_row,
+                 const int32_t* __restrict__ pair_ptr, const uint8_t* __restrict__ node_side,
+                 const double* __restrict__ pair_M, const double* __restrict__ pair_K,
+                 const int32_t* __restrict__ contrib_ptr, const int32_t* __restrict__ contrib_cell,
+                 const double* __restrict__ contrib_k, const double* __restrict__ cbar,
+                 const int32_t* __restrict__ rowptr, double* __restrict__ vals) {
+    int64_t p = (int64_t)blockIdx.x * NT + threadIdx.x;
+    if (p >= n_pairs) return;
+    const int n = pair_row[p];
+    const int p0 = pair_ptr[n];
+    const int q = (int)(p - p0);
+    const int deg = pair_ptr[n + 1] - p0;
+    const int side = node_side[n];
+    double S0 = 0, S1 = 0, S2 = 0;
+    const int c1 = contrib_ptr[p + 1];
+    for (int c = contrib_ptr[p]; c < c1; ++c) {
+        const int cell = contrib_cell[c];
+        const double k = contrib_k[c];
+        S0 += k * cbar[cell];
+        S1 += k * cbar[(size_t)n_c + cell];
+        S2 += k * cbar[(size_t)2 * n_c + cell];
+    }
+    const double S[3] = {S0, S1, S2};
+    const double M = pair_M[p], K = pair_K[p];
+    double phiphi = 0.0;
+    if (!PRECOND) {
+        const int rphi = rowptr[4 * n + 3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double D = side ? P.De[j] : P.Di[j];
+            const double z = P.z[j];
+            const int rj = rowptr[4 * n + j];
+            vals[rj + 2 * q] = M + P.dt * D * K;
+            vals[rj + 2 * q + 1] = P.dt * D * z / P.psi * S[j];
+            vals[rphi + 4 * q + j] = P.dt * z * D * K;
+            phiphi += P.dt * D * z * z / P.psi * S[j];
+        }
+        vals[rphi + 4 * q + 3] = phiphi;
+    } else {
+        const int64_t base = (int64_t)4 * p0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double D = side ? P.De[j] : P.Di[j];
+            const double z = P.z[j];
+            vals[base + (int64_t)j * deg + q] = M + P.dt * D * K;
+            phiphi += P.dt * D * z * z / P.psi * S[j];
+        }
+        vals[base + (int64_t)3 * deg + q] = phiphi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// membrane-program interpreter (one quadrature point)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double powi_d(double x, int e) {
+    bool neg = e < 0;
+    unsigned u = neg ? (unsigned)(-e) : (unsigned)e;
+    double r = 1.0;
+    while (u) {
+        if (u & 1u) r *= x;
+        x *= x;
+        u >>= 1;
+    }
+    return neg ? 1.0 / r : r;
+}
+
+__device__ void run_program(const int32_t* __restrict__ code, int n_instr, const double* __restrict__ consts,
+                            const double* ki, const double* ke, double phim, const double* aux, const double* xq,
+                            double* Iout) {
+    double reg[KNP_MAX_PROG_REGS];
+    for (int i = 0; i < n_instr; ++i) {
+        const int op = code[4 * i], d = code[4 * i + 1], a = code[4 * i + 2], b = code[4 * i + 3];
+        switch (op) {
+            case KNP_OP_CONST: reg[d] = consts[a]; break;
+            case KNP_OP_KI: reg[d] = ki[a]; break;
+            case KNP_OP_KE: reg[d] = ke[a]; break;
+            case KNP_OP_PHIM: reg[d] = phim; break;
+            case KNP_OP_AUX: reg[d] = aux[a]; break;
+            case KNP_OP_X: reg[d] = xq[a]; break;
+            case KNP_OP_ADD: reg[d] = reg[a] + reg[b]; break;
+            case KNP_OP_SUB: reg[d] = reg[a] - reg[b]; break;
+            case KNP_OP_MUL: reg[d] = reg[a] * reg[b]; break;
+            case KNP_OP_DIV: reg[d] = reg[a] / reg[b]; break;
+            case KNP_OP_NEG: reg[d] = -reg[a]; break;
+            case KNP_OP_POW: reg[d] = pow(reg[a], reg[b]); break;
+            case KNP_OP_LN: reg[d] = log(reg[a]); break;
+            case KNP_OP_EXP: reg[d] = exp(reg[a]); break;
+            case KNP_OP_SQRT: reg[d] = sqrt(reg[a]); break;
+            case KNP_OP_MAX: reg[d] = fmax(reg[a], reg[b]); break;
+            case KNP_OP_MIN: reg[d] = fmin(reg[a], reg[b]); break;
+            case KNP_OP_ABS: reg[d] = fabs(reg[a]); break;
+            case KNP_OP_LT: reg[d] = reg[a] < reg[b] ? 1.0 : 0.0; break;
+            case KNP_OP_GT: reg[d] = reg[a] > reg[b] ? 1.0 : 0.0; break;
+            case KNP_OP_LE: reg[d] = reg[a] <= reg[b] ? 1.0 : 0.0; break;
+            case KNP_OP_GE: reg[d] = reg[a] >= reg[b] ? 1.0 : 0.0; break;
+            case KNP_OP_EQ: reg[d] = reg[a] == reg[b] ? 1.0 : 0.0; break;
+            case KNP_OP_AND: reg[d] = (reg[a] != 0.0 && reg[b] != 0.0) ? 1.0 : 0.0; break;
+            case KNP_OP_OR: reg[d] = (reg[a] != 0.0 || reg[b] != 0.0) ? 1.0 : 0.0; break;
+            case KNP_OP_NOT: reg[d] = reg[a] != 0.0 ? 0.0 : 1.0; break;
+            case KNP_OP_SEL: reg[d] = reg[a] != 0.0 ? reg[b] : reg[d]; break;
+            case KNP_OP_OUT: Iout[a] += reg[b]; break;
+            case KNP_OP_MOV: reg[d] = reg[a]; break;
+            case KNP_OP_POWI: reg[d] = powi_d(reg[a], b); break;
+            default: break;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: membrane facet quadrature.  One thread per facet.
+//   fmat[(k*NPK + ab)*n_g + g], k = 0..2 intra ions, 3..5 extra ions : M_Gamma[alpha^k C_M/(F z_k)]
+//   fvec[(k*DIM + a)*n_g + g],  k = 0..2 intra, 3..5 extra, 6 potential
+// ------------------------------------------------------------------------------------------
+template <int DIM, bool MAT, bool VEC>
+__global__ void __launch_bounds__(NT)
+k_gamma_facets(int n_g, int n_q, DevParams P, const int32_t* __restrict__ fv, const double* __restrict__ fmeas,
+               const double* __restrict__ qp, const double* __restrict__ qw, FieldPtrs f, int n_aux,
+               const double* __restrict__ coords, const int32_t* __restrict__ gamma_prog,
+               const int32_t* const* __restrict__ prog_code, const int32_t* __restrict__ prog_len,
+               const double* const* __restrict__ prog_consts, double* __restrict__ fmat,
+               double* __restrict__ fvec) {
+    constexpr int NPK = DIM * (DIM + 1) / 2;
+    const int g = blockIdx.x * NT + threadIdx.x;
+    if (g >= n_g) return;
+    int v[DIM];
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) v[a] = fv[(size_t)g * DIM + a];
+    double ki[3][DIM], ke[3][DIM], pm[DIM];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) {
+            ki[j][a] = f.ki[j][v[a]];
+            ke[j][a] = f.ke[j][v[a]];
+        }
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) pm[a] = f.phim[v[a]];
+    const double meas = fmeas[g];
+    double am[MAT ? 6 : 1][MAT ? NPK : 1];
+    double av[VEC ? 7 : 1][VEC ? DIM : 1];
+    if (MAT) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+#pragma unroll
+            for (int i = 0; i < NPK; ++i) am[k][i] = 0.0;
+    }
+    if (VEC) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+#pragma unroll
+            for (int a = 0; a < DIM; ++a) av[k][a] = 0.0;
+    }
+    const int prog = VEC ? gamma_prog[g] : 0;
+    for (int q = 0; q < n_q; ++q) {
+        double lam[DIM];
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) lam[a] = qp[q * DIM + a];
+        const double w = qw[q] * meas;
+        double kiq[3], keq[3], phq = 0.0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double si = 0.0, se = 0.0;
+#pragma unroll
+            for (int a = 0; a < DIM; ++a) {
+                si += lam[a] * ki[j][a];
+                se += lam[a] * ke[j][a];
+            }
+            kiq[j] = si;
+            keq[j] = se;
+        }
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) phq += lam[a] * pm[a];
+        double deni = 0.0, dene = 0.0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            deni += P.Di[j] * P.z[j] * P.z[j] * kiq[j];
+            dene += P.De[j] * P.z[j] * P.z[j] * keq[j];
+        }
+        double ali[3], ale[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            ali[j] = P.Di[j] * P.z[j] * P.z[j] * kiq[j] / deni;
+            ale[j] = P.De[j] * P.z[j] * P.z[j] * keq[j] / dene;
+        }
+        if (MAT) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double wi = w * ali[j] * P.C_M / (P.F * P.z[j]);
+                const double we = w * ale[j] * P.C_M / (P.F * P.z[j]);
+                int idx = 0;
+#pragma unroll
+                for (int a = 0; a < DIM; ++a)
+#pragma unroll
+                    for (int b = a; b < DIM; ++b) {
+                        const double ll = lam[a] * lam[b];
+                        am[j][idx] += wi * ll;
+                        am[3 + j][idx] += we * ll;
+                        ++idx;
+                    }
+            }
+        }
+        if (VEC) {
+            double auxq[KNP_MAX_AUX], xq[3] = {0, 0, 0}, Iout[3] = {0, 0, 0};
+            for (int k = 0; k < n_aux; ++k) {
+                double s = 0.0;
+#pragma unroll
+                for (int a = 0; a < DIM; ++a) s += lam[a] * f.aux[k][v[a]];
+                auxq[k] = s;
+            }
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) {
+                double s = 0.0;
+#pragma unroll
+                for (int a = 0; a < DIM; ++a) s += lam[a] * coords[(size_t)v[a] * DIM + d];
+                xq[d] = s;
+            }
+            run_program(prog_code[prog], prog_len[prog], prog_consts[prog], kiq, keq, phq, auxq, xq, Iout);
+            const double Itot = Iout[0] + Iout[1] + Iout[2];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double gi = w * (P.dt * Iout[j] - ali[j] * P.C_M * phq) / (P.F * P.z[j]);
+                const double ge = w * (P.dt * Iout[j] - ale[j] * P.C_M * phq) / (P.F * P.z[j]);
+#pragma unroll
+                for (int a = 0; a < DIM; ++a) {
+                    av[j][a] += gi * lam[a];
+                    av[3 + j][a] += ge * lam[a];
+                }
+            }
+            const double gp = w * (P.dt * Itot - P.C_M * phq) / P.F;
+#pragma unroll
+            for (int a = 0; a < DIM; ++a) av[6][a] += gp * lam[a];
+        }
+    }
+    if (MAT) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+#pragma unroll
+            for (int i = 0; i < NPK; ++i) fmat[((size_t)k * NPK + i) * n_g + g] = am[k][i];
+    }
+    if (VEC) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+#pragma unroll
+            for (int a = 0; a < DIM; ++a) fvec[((size_t)k * DIM + a) * n_g + g] = av[k][a];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2b: membrane coupling entries, one thread per membrane vertex pair
+// ------------------------------------------------------------------------------------------
+template <bool PRECOND>
+__global__ void __launch_bounds__(NT)
+k_gamma_pairs(int64_t n_gp, int n_g, int dim, DevParams P, const int32_t* __restrict__ grow,
+              const int32_t* __restrict__ gptr, const int32_t* __restrict__ gv_node_i,
+              const int32_t* __restrict__ gv_node_e, const int32_t* __restrict__ gq_i,
+              const int32_t* __restrict__ gq_e, const int32_t* __restrict__ gcptr,
+              const int32_t* __restrict__ gc_facet, const int32_t* __restrict__ gc_lab,
+              const double* __restrict__ fmeas, const double* __restrict__ fmat,
+              const int32_t* __restrict__ pair_ptr, const int32_t* __restrict__ rowptr, double* __restrict__ vals) {
+    int64_t s = (int64_t)blockIdx.x * NT + threadIdx.x;
+    if (s >= n_gp) return;
+    const int A = grow[s];
+    const int r = (int)(s - gptr[A]);
+    const int ni = gv_node_i[A], ne = gv_node_e[A];
+    const int npk = dim * (dim + 1) / 2;
+    double m[6] = {0, 0, 0, 0, 0, 0};
+    double m0 = 0.0;
+    const double mref = 1.0 / (dim * (dim + 1.0));
+    for (int c = gcptr[s]; c < gcptr[s + 1]; ++c) {
+        const int fct = gc_facet[c];
+        int la = gc_lab[c] >> 2, lb = gc_lab[c] & 3;
+        m0 += fmeas[fct] * mref * (la == lb ? 2.0 : 1.0);
+        if (!PRECOND) {
+            if (la > lb) { int t = la; la = lb; lb = t; }
+            const int idx = la * dim - la * (la - 1) / 2 + (lb - la);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) m[k] += fmat[((size_t)k * npk + idx) * n_g + fct];
+        }
+    }
+    m0 *= P.C_M / P.F;
+    const int pi0 = pair_ptr[ni], pe0 = pair_ptr[ne];
+    const int degi = pair_ptr[ni + 1] - pi0, dege = pair_ptr[ne + 1] - pe0;
+    const int qi = gq_i[s], qe = gq_e[s];
+    if (!PRECOND) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int ri = rowptr[4 * ni + j], re = rowptr[4 * ne + j];
+            vals[ri + 2 * qi + 1] += m[j];
+            vals[ri + 2 * degi + r] = -m[j];
+            vals[re + 2 * qe + 1] += m[3 + j];
+            vals[re + 2 * dege + r] = -m[3 + j];
+        }
+        const int ri = rowptr[4 * ni + 3], re = rowptr[4 * ne + 3];
+        vals[ri + 4 * qi + 3] += m0;
+        vals[ri + 4 * degi + r] = -m0;
+        vals[re + 4 * qe + 3] += m0;
+        vals[re + 4 * dege + r] = -m0;
+    } else {
+        vals[(int64_t)4 * pi0 + (int64_t)3 * degi + qi] -= m0;   // KNPEMIx_problem.py:737
+        vals[(int64_t)4 * pe0 + (int64_t)3 * dege + qe] -= m0;   // KNPEMIx_problem.py:738
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3: right-hand side, one thread per owned node
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(NT)
+k_rhs(int n_nodes_owned, int n_g, int dim, double dt, const int32_t* __restrict__ node_vertex,
+      const uint8_t* __restrict__ node_side, const int32_t* __restrict__ pair_ptr,
+      const int32_t* __restrict__ pair_col, const double* __restrict__ pair_M, FieldPtrs f, FieldPtrs src,
+      int have_src, const int32_t* __restrict__ node_gv, const int32_t* __restrict__ gdiag,
+      const int32_t* __restrict__ gcptr, const int32_t* __restrict__ gc_facet,
+      const int32_t* __restrict__ gc_lab, const double* __restrict__ fvec, double* __restrict__ b) {
+    const int n = blockIdx.x * NT + threadIdx.x;
+    if (n >= n_nodes_owned) return;
+    const int side = node_side[n];
+    double acc[3] = {0, 0, 0};
+    const double* k0 = side ? f.ke[0] : f.ki[0];
+    const double* k1 = side ? f.ke[1] : f.ki[1];
+    const double* k2 = side ? f.ke[2] : f.ki[2];
+    for (int p = pair_ptr[n]; p < pair_ptr[n + 1]; ++p) {
+        const int vb = node_vertex[pair_col[p]];
+        const double M = pair_M[p];
+        acc[0] += M * k0[vb];
+        acc[1] += M * k1[vb];
+        acc[2] += M * k2[vb];
+        if (have_src) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double* s = side ? src.ke[j] : src.ki[j];
+                if (s) acc[j] += dt * M * s[vb];
+            }
+        }
+    }
+    double accp = 0.0;
+    const int A = node_gv[n];
+    if (A >= 0) {
+        const int s = gdiag[A];
+        const double sg = side ? 1.0 : -1.0;
+        for (int c = gcptr[s]; c < gcptr[s + 1]; ++c) {
+            const int fct = gc_facet[c];
+            const int la = gc_lab[c] >> 2;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[j] += sg * fvec[((size_t)((side ? 3 : 0) + j) * dim + la) * n_g + fct];
+            accp += sg * fvec[((size_t)6 * dim + la) * n_g + fct];
+        }
+    }
+    b[(size_t)4 * n + 0] = acc[0];
+    b[(size_t)4 * n + 1] = acc[1];
+    b[(size_t)4 * n + 2] = acc[2];
+    b[(size_t)4 * n + 3] = accp;
+}
+
+// ------------------------------------------------------------------------------------------
+// K4: CSR SpMV, L lanes per row.  mode 0: y = A x ; mode 1: y = b - A x
+// ------------------------------------------------------------------------------------------
+template <int L, int MODE>
+__global__ void __launch_bounds__(NT)
+k_spmv(int n_rows, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci, const double* __restrict__ v,
+       const double* __restrict__ x, const double* __restrict__ b, double* __restrict__ y) {
+    const int gid = blockIdx.x * NT + threadIdx.x;
+    const int row = gid / L;
+    const int lane = threadIdx.x & (L - 1);
+    double s = 0.0;
+    if (row < n_rows) {
+        const int e = rp[row + 1];
+        for (int k = rp[row] + lane; k < e; k += L) s += v[k] * x[ci[k]];
+    }
+#pragma unroll
+    for (int o = L >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, L);
+    if (lane == 0 && row < n_rows) y[row] = MODE ? b[row] - s : s;
+}
+
+template <int MODE>
+static void launch_spmv(hipStream_t st, int lanes, int n_rows, const int32_t* rp, const int32_t* ci,
+                        const double* v, const double* x, const double* b, double* y) {
+    if (n_rows <= 0) return;
+    switch (lanes) {
+        case 2: hipLaunchKernelGGL((k_spmv<2, MODE>), dim3(nblocks((int64_t)n_rows * 2)), dim3(NT), 0, st, n_rows, rp, ci, v, x, b, y); break;
+        case 4: hipLaunchKernelGGL((k_spmv<4, MODE>), dim3(nblocks((int64_t)n_rows * 4)), dim3(NT), 0, st, n_rows, rp, ci, v, x, b, y); break;
+        case 8: hipLaunchKernelGGL((k_spmv<8, MODE>), dim3(nblocks((int64_t)n_rows * 8)), dim3(NT), 0, st, n_rows, rp, ci, v, x, b, y); break;
+        case 16: hipLaunchKernelGGL((k_spmv<16, MODE>), dim3(nblocks((int64_t)n_rows * 16)), dim3(NT), 0, st, n_rows, rp, ci, v, x, b, y); break;
+        case 32: hipLaunchKernelGGL((k_spmv<32, MODE>), dim3(nblocks((int64_t)n_rows * 32)), dim3(NT), 0, st, n_rows, rp, ci, v, x, b, y); break;
+        default: hipLaunchKernelGGL((k_spmv<64, MODE>), dim3(nblocks((int64_t)n_rows * 64)), dim3(NT), 0, st, n_rows, rp, ci, v, x, b, y); break;
+    }
+}
+
+static int pick_lanes(double avg_nnz_per_row) {
+    if (avg_nnz_per_row <= 3.0) return 2;
+    if (avg_nnz_per_row <= 6.0) return 4;
+    if (avg_nnz_per_row <= 14.0) return 8;
+    if (avg_nnz_per_row <= 40.0) return 16;
+    if (avg_nnz_per_row <= 96.0) return 32;
+    return 64;
+}
+
+// ------------------------------------------------------------------------------------------
+// K5/K6: orthogonalisation and vector kernels
+// ------------------------------------------------------------------------------------------
+// partial[(i)*RED_BLOCKS + blk] = sum over this block's elements of V_i . w, i = i0 .. i0+G-1 (< m)
+template <int G>
+__global__ void __launch_bounds__(NT)
+k_multi_dot(int n, int64_t ldv, int i0, int m, const double* __restrict__ V, const double* __restrict__ w,
+            double* __restrict__ partial) {
+    __shared__ double sm[NT / 64];
+    double acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = 0.0;
+    for (int e = blockIdx.x * NT + threadIdx.x; e < n; e += gridDim.x * NT) {
+        const double we = w[e];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (i0 + g < m) acc[g] += V[(int64_t)(i0 + g) * ldv + e] * we;
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        double r = block_sum(acc[g], sm);
+        if (threadIdx.x == 0 && i0 + g < m) partial[(size_t)(i0 + g) * RED_BLOCKS + blockIdx.x] = r;
+    }
+}
+
+// out[slot0 + i] = sum_b partial[i*RED_BLOCKS + b], one block per i
+__global__ void __launch_bounds__(NT) k_reduce_partials(int nb, const double* __restrict__ partial,
+                                                        double* __restrict__ out, int slot0) {
+    __shared__ double sm[NT / 64];
+    const int i = blockIdx.x;
+    double a = 0.0;
+    for (int b = threadIdx.x; b < nb; b += NT) a += partial[(size_t)i * RED_BLOCKS + b];
+    a = block_sum(a, sm);
+    if (threadIdx.x == 0) out[slot0 + i] = a;
+}
+
+// w -= sum_i h[i] V_i ; partial[blk] = sum w^2 over the block
+__global__ void __launch_bounds__(NT)
+k_update_norm(int n, int64_t ldv, int m, const double* __restrict__ V, const double* __restrict__ h,
+              double* __restrict__ w, double* __restrict__ partial) {
+    __shared__ double sm[NT / 64];
+    double acc = 0.0;
+    for (int e = blockIdx.x * NT + threadIdx.x; e < n; e += gridDim.x * NT) {
+        double we = w[e];
+        for (int i = 0; i < m; ++i) we -= h[i] * V[(int64_t)i * ldv + e];
+        w[e] = we;
+        acc += we * we;
+    }
+    acc = block_sum(acc, sm);
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+// partial[blk] = sum a.b
+__global__ void __launch_bounds__(NT) k_dot(int n, const double* __restrict__ a, const double* __restrict__ b,
+                                            double* __restrict__ partial) {
+    __shared__ double sm[NT / 64];
+    double acc = 0.0;
+    for (int e = blockIdx.x * NT + threadIdx.x; e < n; e += gridDim.x * NT) acc += a[e] * b[e];
+    acc = block_sum(acc, sm);
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+// out = in / sqrt(*nrm2)
+__global__ void __launch_bounds__(NT) k_scale_rsqrt(int n, const double* __restrict__ in, const double* __restrict__ nrm2,
+                                                    double* __restrict__ out) {
+    const double inv = 1.0 / sqrt(*nrm2);
+    for (int e = blockIdx.x * NT + threadIdx.x; e < n; e += gridDim.x * NT) out[e] = in[e] * inv;
+}
+
+// x += sum_i y[i] V_i
+__global__ void __launch_bounds__(NT) k_lincomb(int n, int64_t ldv, int m, const double* __restrict__ V,
+                                                const double* __restrict__ y, double* __restrict__ x) {
+    for (int e = blockIdx.x * NT + threadIdx.x; e < n; e += gridDim.x * NT) {
+        double xe = x[e];
+        for (int i = 0; i < m; ++i) xe += y[i] * V[(int64_t)i * ldv + e];
+        x[e] = xe;
+    }
+}
+
+__global__ void __launch_bounds__(NT) k_axpy(int n, double a, const double* __restrict__ x, double* __restrict__ y) {
+    for (int e = blockIdx.x * NT + threadIdx.x; e < n; e += gridDim.x * NT) y[e] += a * x[e];
+}
+__global__ void __launch_bounds__(NT) k_fill(int n, double a, double* __restrict__ y) {
+    for (int e = blockIdx.x * NT + threadIdx.x; e < n; e += gridDim.x * NT) y[e] = a;
+}
+// y = d .* x
+__global__ void __launch_bounds__(NT) k_diag_scale(int n, double a, const double* __restrict__ d,
+                                                   const double* __restrict__ x, double* __restrict__ y) {
+    for (int e = blockIdx.x * NT + threadIdx.x; e < n; e += gridDim.x * NT) y[e] = a * d[e] * x[e];
+}
+
+// ------------------------------------------------------------------------------------------
+// K8: gauge projection
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(NT) k_phi_sum(int n_nodes, const double* __restrict__ z, double* __restrict__ partial) {
+    __shared__ double sm[NT / 64];
+    double acc = 0.0;
+    for (int n = blockIdx.x * NT + threadIdx.x; n < n_nodes; n += gridDim.x * NT) acc += z[(size_t)4 * n + 3];
+    acc = block_sum(acc, sm);
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+__global__ void __launch_bounds__(NT) k_phi_sub(int n_nodes, const double* __restrict__ sum, double inv_count,
+                                                double* __restrict__ z) {
+    const double mean = (*sum) * inv_count;
+    for (int n = blockIdx.x * NT + threadIdx.x; n < n_nodes; n += gridDim.x * NT) z[(size_t)4 * n + 3] -= mean;
+}
+__global__ void __launch_bounds__(NT) k_fill_phi(int n_nodes, double val, double* __restrict__ z) {
+    for (int n = blockIdx.x * NT + threadIdx.x; n < n_nodes; n += gridDim.x * NT) {
+        z[(size_t)4 * n + 0] = 0.0;
+        z[(size_t)4 * n + 1] = 0.0;
+        z[(size_t)4 * n + 2] = 0.0;
+        z[(size_t)4 * n + 3] = val;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K7: vertex-block Jacobi built from A.  blk[n*16 + {0..2: d_j, 3..5: u_j, 6..8: v_j, 9: s,
+//                                         10..12: ux_j (k rows -> other side's phi), 13: sx}]
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(NT)
+k_vbj_extract(int n_nodes_owned, const int32_t* __restrict__ pair_ptr, const int32_t* __restrict__ pair_col,
+              const int32_t* __restrict__ rowptr, const double* __restrict__ vals,
+              const int32_t* __restrict__ node_gv, const int32_t* __restrict__ gptr,
+              const int32_t* __restrict__ gdiag, double* __restrict__ blk) {
+    const int n = blockIdx.x * NT + threadIdx.x;
+    if (n >= n_nodes_owned) return;
+    const int p0 = pair_ptr[n], deg = pair_ptr[n + 1] - p0;
+    int qs = 0;
+    for (int q = 0; q < deg; ++q)
+        if (pair_col[p0 + q] == n) { qs = q; break; }
+    double* o = blk + (size_t)16 * n;
+    const int rphi = rowptr[4 * n + 3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int rj = rowptr[4 * n + j];
+        o[j] = vals[rj + 2 * qs];
+        o[3 + j] = vals[rj + 2 * qs + 1];
+        o[6 + j] = vals[rphi + 4 * qs + j];
+    }
+    o[9] = vals[rphi + 4 * qs + 3];
+    const int A = node_gv[n];
+    if (A >= 0) {
+        const int rs = gdiag[A] - gptr[A];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) o[10 + j] = vals[rowptr[4 * n + j] + 2 * deg + rs];
+        o[13] = vals[rphi + 4 * deg + rs];
+    } else {
+        o[10] = o[11] = o[12] = o[13] = 0.0;
+    }
+}
+
+__global__ void __launch_bounds__(NT)
+k_vbj_apply(int n_nodes_owned, const uint8_t* __restrict__ node_side, const int32_t* __restrict__ node_gv,
+            const int32_t* __restrict__ gv_node_e, const double* __restrict__ blk, const double* __restrict__ r,
+            double* __restrict__ z) {
+    const int n = blockIdx.x * NT + threadIdx.x;
+    if (n >= n_nodes_owned) return;
+    const int A = node_gv[n];
+    const double* B = blk + (size_t)16 * n;
+    if (A < 0) {
+        double rp = r[(size_t)4 * n + 3], S = B[9];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            rp -= B[6 + j] * r[(size_t)4 * n + j] / B[j];
+            S -= B[6 + j] * B[3 + j] / B[j];
+        }
+        const double yp = rp / S;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) z[(size_t)4 * n + j] = (r[(size_t)4 * n + j] - B[3 + j] * yp) / B[j];
+        z[(size_t)4 * n + 3] = yp;
+        return;
+    }
+    if (node_side[n] != 0) return;  // the intra node of a membrane vertex solves the coupled 8x8
+    const int m = gv_node_e[A];
+    const double* C = blk + (size_t)16 * m;
+    double a11 = B[9], a12 = B[13], a21 = C[13], a22 = C[9];
+    double r1 = r[(size_t)4 * n + 3], r2 = r[(size_t)4 * m + 3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double vi = B[6 + j] / B[j], ve = C[6 + j] / C[j];
+        a11 -= vi * B[3 + j];
+        a12 -= vi * B[10 + j];
+        r1 -= vi * r[(size_t)4 * n + j];
+        a22 -= ve * C[3 + j];
+        a21 -= ve * C[10 + j];
+        r2 -= ve * r[(size_t)4 * m + j];
+    }
+    const double det = a11 * a22 - a12 * a21;
+    const double pi = (a22 * r1 - a12 * r2) / det;
+    const double pe = (a11 * r2 - a21 * r1) / det;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        z[(size_t)4 * n + j] = (r[(size_t)4 * n + j] - B[3 + j] * pi - B[10 + j] * pe) / B[j];
+        z[(size_t)4 * m + j] = (r[(size_t)4 * m + j] - C[3 + j] * pe - C[10 + j] * pi) / C[j];
+    }
+    z[(size_t)4 * n + 3] = pi;
+    z[(size_t)4 * m + 3] = pe;
+}
+
+// ------------------------------------------------------------------------------------------
+// AMG pieces
+// ------------------------------------------------------------------------------------------
+// d = c1*d + c2 * Dinv*(b - A x)     (L lanes per row); FIRST: x == 0, d = c2*Dinv*b
+template <int L>
+__global__ void __launch_bounds__(NT)
+k_cheby_step(int n_rows, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci, const double* __restrict__ v,
+             const double* __restrict__ dinv, const double* __restrict__ b, const double* __restrict__ x,
+             double c1, double c2, double* __restrict__ d) {
+    const int gid = blockIdx.x * NT + threadIdx.x;
+    const int row = gid / L;
+    const int lane = threadIdx.x & (L - 1);
+    double s = 0.0;
+    if (row < n_rows) {
+        const int e = rp[row + 1];
+        for (int k = rp[row] + lane; k < e; k += L) s += v[k] * x[ci[k]];
+    }
+#pragma unroll
+    for (int o = L >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, L);
+    if (lane == 0 && row < n_rows) d[row] = (c1 != 0.0 ? c1 * d[row] : 0.0) + c2 * dinv[row] * (b[row] - s);
+}
+static void launch_cheby(hipStream_t st, int lanes, int n_rows, const int32_t* rp, const int32_t* ci, const double* v,
+                         const double* dinv, const double* b, const double* x, double c1, double c2, double* d) {
+    if (n_rows <= 0) return;
+    switch (lanes) {
+        case 2: hipLaunchKernelGGL((k_cheby_step<2>), dim3(nblocks((int64_t)n_rows * 2)), dim3(NT), 0, st, n_rows, rp, ci, v, dinv, b, x, c1, c2, d); break;
+        case 4: hipLaunchKernelGGL((k_cheby_step<4>), dim3(nblocks((int64_t)n_rows * 4)), dim3(NT), 0, st, n_rows, rp, ci, v, dinv, b, x, c1, c2, d); break;
+        case 8: hipLaunchKernelGGL((k_cheby_step<8>), dim3(nblocks((int64_t)n_rows * 8)), dim3(NT), 0, st, n_rows, rp, ci, v, dinv, b, x, c1, c2, d); break;
+        case 16: hipLaunchKernelGGL((k_cheby_step<16>), dim3(nblocks((int64_t)n_rows * 16)), dim3(NT), 0, st, n_rows, rp, ci, v, dinv, b, x, c1, c2, d); break;
+        case 32: hipLaunchKernelGGL((k_cheby_step<32>), dim3(nblocks((int64_t)n_rows * 32)), dim3(NT), 0, st, n_rows, rp, ci, v, dinv, b, x, c1, c2, d); break;
+        default: hipLaunchKernelGGL((k_cheby_step<64>), dim3(nblocks((int64_t)n_rows * 64)), dim3(NT), 0, st, n_rows, rp, ci, v, dinv, b, x, c1, c2, d); break;
+    }
+}
+// y = M x, dense row-major n x n, one wave per row
+__global__ void __launch_bounds__(NT) k_dense_matvec(int n, const double* __restrict__ M, const double* __restrict__ x,
+                                                     double* __restrict__ y) {
+    const int row = (blockIdx.x * NT + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    double s = 0.0;
+    if (row < n)
+        for (int k = lane; k < n; k += 64) s += M[(size_t)row * n + k] * x[k];
+    s = wave_sum(s);
+    if (lane == 0 && row < n) y[row] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// K9: Hodgkin-Huxley gating update (KNPEMIx_ionic_model.py:605-671)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(NT)
+k_hh_update(int count, const double* __restrict__ phi_m, double* __restrict__ gn, double* __restrict__ gm,
+            double* __restrict__ gh, double dt, double phi_rest, int rush_larsen, int substeps) {
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= count) return;
+    const double V = 1000.0 * (phi_m[i] - phi_rest);
+    const double an = 0.01e3 * (10.0 - V) / (exp((10.0 - V) / 10.0) - 1.0);
+    const double bn = 0.125e3 * exp(-V / 80.0);
+    const double am = 0.1e3 * (25.0 - V) / (exp((25.0 - V) / 10.0) - 1.0);
+    const double bm = 4.0e3 * exp(-V / 18.0);
+    const double ah = 0.07e3 * exp(-V / 20.0);
+    const double bh = 1.0e3 / (exp((30.0 - V) / 10.0) + 1.0);
+    double n = gn[i], m = gm[i], h = gh[i];
+    if (rush_larsen) {
+        // `substeps` frozen-coefficient exponential steps of dt/substeps == one exact step of dt
+        const double tn = an + bn, tm = am + bm, th = ah + bh;
+        const double ninf = an / tn, minf = am / tm, hinf = ah / th;
+        n = ninf + (n - ninf) * exp(-dt * tn);
+        m = minf + (m - minf) * exp(-dt * tm);
+        h = hinf + (h - hinf) * exp(-dt * th);
+    } else {
+        const double dto = dt / substeps;
+        for (int s = 0; s < substeps; ++s) {
+            n += dto * an * (1.0 - n) - dto * bn * n;
+            m += dto * am * (1.0 - m) - dto * bm * m;
+            h += dto * ah * (1.0 - h) - dto * bh * h;
+        }
+    }
+    gn[i] = n;
+    gm[i] = m;
+    gh[i] = h;
+}
+
+// ------------------------------------------------------------------------------------------
+// K10: pack / unpack
+// ------------------------------------------------------------------------------------------
+struct OutPtrs {
+    double* ki[3];
+    double* ke[3];
+    double *phi_i, *phi_e, *phi_m;
+};
+__global__ void __launch_bounds__(NT)
+k_pack(int n_nodes, const int32_t* __restrict__ node_vertex, const uint8_t* __restrict__ node_side, OutPtrs f,
+       double* __restrict__ x) {
+    const int n = blockIdx.x * NT + threadIdx.x;
+    if (n >= n_nodes) return;
+    const int v = node_vertex[n];
+    const int s = node_side[n];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) x[(size_t)4 * n + j] = (s ? f.ke[j] : f.ki[j])[v];
+    x[(size_t)4 * n + 3] = (s ? f.phi_e : f.phi_i)[v];
+}
+__global__ void __launch_bounds__(NT)
+k_unpack(int n_v, const int32_t* __restrict__ node_i, const int32_t* __restrict__ node_e, const double* __restrict__ x,
+         OutPtrs f) {
+    const int v = blockIdx.x * NT + threadIdx.x;
+    if (v >= n_v) return;
+    const int ni = node_i[v], ne = node_e[v];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        f.ki[j][v] = ni >= 0 ? x[(size_t)4 * ni + j] : 0.0;
+        f.ke[j][v] = ne >= 0 ? x[(size_t)4 * ne + j] : 0.0;
+    }
+    const double pi = ni >= 0 ? x[(size_t)4 * ni + 3] : 0.0;
+    const double pe = ne >= 0 ? x[(size_t)4 * ne + 3] : 0.0;
+    f.phi_i[v] = pi;
+    f.phi_e[v] = pe;
+    f.phi_m[v] = pi - pe;
+}
+
+// L2 norms: partial[blk] (intra), partial[RED_BLOCKS + blk] (extra)
+template <int DIM>
+__global__ void __launch_bounds__(NT)
+k_l2(int n_c, const int32_t* __restrict__ cells, const uint8_t* __restrict__ side, const double* __restrict__ coords,
+     const double* __restrict__ phi_i, const double* __restrict__ phi_e, double* __restrict__ partial) {
+    __shared__ double sm[NT / 64];
+    double acc[2] = {0.0, 0.0};
+    for (int c = blockIdx.x * NT + threadIdx.x; c < n_c; c += gridDim.x * NT) {
+        int v[DIM + 1];
+#pragma unroll
+        for (int a = 0; a <= DIM; ++a) v[a] = cells[(size_t)c * (DIM + 1) + a];
+        double e[DIM][DIM];
+#pragma unroll
+        for (int a = 0; a < DIM; ++a)
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) e[a][d] = coords[(size_t)v[a + 1] * DIM + d] - coords[(size_t)v[0] * DIM + d];
+        double det;
+        if (DIM == 2) {
+            det = e[0][0] * e[1][1] - e[0][1] * e[1][0];
+        } else {
+            det = e[0][0] * (e[1][1] * e[2][2] - e[1][2] * e[2][1]) - e[0][1] * (e[1][0] * e[2][2] - e[1][2] * e[2][0]) +
+                  e[0][2] * (e[1][0] * e[2][1] - e[1][1] * e[2][0]);
+        }
+        const double vol = fabs(det) / (DIM == 2 ? 2.0 : 6.0);
+        const int s = side[c];
+        const double* u = s ? phi_e : phi_i;
+        double su = 0.0, suu = 0.0;
+#pragma unroll
+        for (int a = 0; a <= DIM; ++a) {
+            const double ua = u[v[a]];
+            su += ua;
+            suu += ua * ua;
+        }
+        // u^T M u with M = vol (1 + delta)/((d+1)(d+2))
+        acc[s] += vol * (su * su + suu) / ((DIM + 1.0) * (DIM + 2.0));
+    }
+    double r0 = block_sum(acc[0], sm);
+    double r1 = block_sum(acc[1], sm);
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = r0;
+        partial[RED_BLOCKS + blockIdx.x] = r1;
+    }
+}
+
+// ==========================================================================================
+// host side
+// ==========================================================================================
+template <typename T>
+static int dev_upload(knp_ctx* ctx, T** dst, const std::vector<T>& src) {
+    *dst = nullptr;
+    size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+    HIPCHK(hipMalloc((void**)dst, bytes));
+    if (!src.empty()) HIPCHK(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return KNP_OK;
+}
+template <typename T>
+static int dev_upload_raw(knp_ctx* ctx, T** dst, const T* src, size_t n) {
+    *dst = nullptr;
+    HIPCHK(hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(T)));
+    if (n) HIPCHK(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return KNP_OK;
+}
+template <typename T>
+static void dev_free(T*& p) {
+    if (p) (void)hipFree((void*)p);
+    p = nullptr;
+}
+
+static DevParams make_params(const knp_ctx* ctx) {
+    DevParams P;
+    P.dt = ctx->dt; P.F = ctx->F; P.C_M = ctx->C_M; P.psi = ctx->psi;
+    for (int j = 0; j < 3; ++j) { P.z[j] = ctx->z[j]; P.Di[j] = ctx->Di[j]; P.De[j] = ctx->De[j]; }
+    return P;
+}
+static FieldPtrs make_fields(const knp_fields* f) {
+    FieldPtrs o;
+    for (int j = 0; j < 3; ++j) { o.ki[j] = f->k_i[j]; o.ke[j] = f->k_e[j]; }
+    o.phim = f->phi_m;
+    for (int k = 0; k < KNP_MAX_AUX; ++k) o.aux[k] = f->aux[k];
+    return o;
+}
+
+// profiling scope: records a pair of events around a group of launches when enabled
+struct ProfScope {
+    knp_ctx* c;
+    hipEvent_t a = nullptr, b = nullptr;
+    int cls;
+    ProfScope(knp_ctx* ctx, int cls_) : c(ctx), cls(cls_) {
+        if (c->prof_on) {
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+            (void)hipEventRecord(a, c->stream);
+        }
+    }
+    ~ProfScope() {
+        if (c->prof_on && a && b) {
+            (void)hipEventRecord(b, c->stream);
+            c->prof_recs.push_back({a, b, cls});
+        }
+    }
+};
+
+static int prof_collect(knp_ctx* ctx) {
+    if (ctx->prof_recs.empty()) return KNP_OK;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (auto& r : ctx->prof_recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            ctx->prof_ms[r.cls] += ms;
+            ctx->prof_n[r.cls] += 1;
+        }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    ctx->prof_recs.clear();
+    return KNP_OK;
+}
+
+extern "C" {
+
+const char* knp_last_error(const knp_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+int knp_create(knp_ctx** out, const knp_mesh_desc* mesh) {
+    if (!out) return KNP_E_ARG;
+    *out = nullptr;
+    knp_ctx* ctx = new (std::nothrow) knp_ctx();
+    if (!ctx) return KNP_E_ALLOC;
+    *out = ctx;  // returned even on failure so that knp_last_error can be read; caller destroys
+    int rc = knp_build_graph(mesh, ctx->g);
+    if (rc != KNP_OK) { ctx->err = ctx->g.error; return rc; }
+    KnpHostGraph& g = ctx->g;
+    HIPCHK(hipGetDevice(&ctx->device));
+    ctx->max_prog = -1;
+    for (int f = 0; f < g.n_g; ++f) {
+        if (mesh->gamma_prog[f] < 0) { ctx->err = "negative gamma_prog id"; return KNP_E_MESH; }
+        ctx->max_prog = std::max(ctx->max_prog, (int)mesh->gamma_prog[f]);
+    }
+    ctx->n_pairs = (int64_t)g.pair_col.size();
+    ctx->n_contrib = (int64_t)g.contrib_cell.size();
+    ctx->n_gp = (int64_t)g.gcol.size();
+    ctx->n_gc = (int64_t)g.gc_facet.size();
+    ctx->nnz = (int64_t)g.colind.size();
+    ctx->n_dof_owned = 4 * g.n_nodes_owned;
+    ctx->n_dof_local = 4 * g.n_nodes;
+    const int dim = g.dim, nv1 = g.nv1;
+    KCHK(dev_upload_raw(ctx, &ctx->d_cells, mesh->cells, (size_t)g.n_c * nv1));
+    KCHK(dev_upload_raw(ctx, &ctx->d_cell_side, mesh->cell_side, (size_t)g.n_c));
+    KCHK(dev_upload_raw(ctx, &ctx->d_coords, mesh->coords, (size_t)g.n_v * dim));
+    KCHK(dev_upload(ctx, &ctx->d_node_vertex, g.node_vertex));
+    KCHK(dev_upload(ctx, &ctx->d_node_side, g.node_side));
+    KCHK(dev_upload(ctx, &ctx->d_node_i, g.node_i));
+    KCHK(dev_upload(ctx, &ctx->d_node_e, g.node_e));
+    KCHK(dev_upload(ctx, &ctx->d_pair_ptr, g.pair_ptr));
+    KCHK(dev_upload(ctx, &ctx->d_pair_col, g.pair_col));
+    KCHK(dev_upload(ctx, &ctx->d_pair_row, g.pair_row));
+    KCHK(dev_upload(ctx, &ctx->d_pair_M, g.pair_M));
+    KCHK(dev_upload(ctx, &ctx->d_pair_K, g.pair_K));
+    KCHK(dev_upload(ctx, &ctx->d_contrib_ptr, g.contrib_ptr));
+    KCHK(dev_upload(ctx, &ctx->d_contrib_cell, g.contrib_cell));
+    KCHK(dev_upload(ctx, &ctx->d_contrib_k, g.contrib_k));
+    KCHK(dev_upload(ctx, &ctx->d_fv, g.fv));
+    KCHK(dev_upload(ctx, &ctx->d_fmeas, g.fmeas));
+    KCHK(dev_upload_raw(ctx, &ctx->d_gamma_prog, mesh->gamma_prog, (size_t)g.n_g));
+    KCHK(dev_upload_raw(ctx, &ctx->d_qp, mesh->q_pts, (size_t)g.n_q * dim));
+    KCHK(dev_upload_raw(ctx, &ctx->d_qw, mesh->q_w, (size_t)g.n_q));
+    KCHK(dev_upload(ctx, &ctx->d_gv_vertex, g.gv_vertex));
+    KCHK(dev_upload(ctx, &ctx->d_gv_node_i, g.gv_node_i));
+    KCHK(dev_upload(ctx, &ctx->d_gv_node_e, g.gv_node_e));
+    KCHK(dev_upload(ctx, &ctx->d_node_gv, g.node_gv));
+    KCHK(dev_upload(ctx, &ctx->d_gptr, g.gptr));
+    KCHK(dev_upload(ctx, &ctx->d_gcol, g.gcol));
+    KCHK(dev_upload(ctx, &ctx->d_grow, g.grow));
+    KCHK(dev_upload(ctx, &ctx->d_gq_i, g.gq_i));
+    KCHK(dev_upload(ctx, &ctx->d_gq_e, g.gq_e));
+    KCHK(dev_upload(ctx, &ctx->d_gdiag, g.gdiag));
+    KCHK(dev_upload(ctx, &ctx->d_gcptr, g.gcptr));
+    KCHK(dev_upload(ctx, &ctx->d_gc_facet, g.gc_facet));
+    KCHK(dev_upload(ctx, &ctx->d_gc_lab, g.gc_lab));
+    KCHK(dev_upload(ctx, &ctx->d_rowptr, g.rowptr));
+    KCHK(dev_upload(ctx, &ctx->d_colind, g.colind));
+    HIPCHK(hipMalloc((void**)&ctx->d_vals, std::max<int64_t>(ctx->nnz, 1) * sizeof(double)));
+    HIPCHK(hipMemset(ctx->d_vals, 0, std::max<int64_t>(ctx->nnz, 1) * sizeof(double)));
+    // P pattern: row (n,f) -> cols (nb,f)
+    {
+        const int no = g.n_nodes_owned;
+        std::vector<int32_t> prp((size_t)4 * no + 1), pci((size_t)4 * ctx->n_pairs);
+        for (int n = 0; n < no; ++n) {
+            const int p0 = g.pair_ptr[n], deg = g.pair_ptr[n + 1] - p0;
+            for (int f = 0; f < 4; ++f) {
+                prp[(size_t)4 * n + f] = 4 * p0 + f * deg;
+                for (int q = 0; q < deg; ++q) pci[(size_t)4 * p0 + (size_t)f * deg + q] = 4 * g.pair_col[p0 + q] + f;
+            }
+        }
+        prp[(size_t)4 * no] = (int32_t)(4 * ctx->n_pairs);
+        KCHK(dev_upload(ctx, &ctx->d_p_rowptr, prp));
+        KCHK(dev_upload(ctx, &ctx->d_p_colind, pci));
+        HIPCHK(hipMalloc((void**)&ctx->d_p_vals, std::max<int64_t>(4 * ctx->n_pairs, 1) * sizeof(double)));
+        HIPCHK(hipMemset(ctx->d_p_vals, 0, std::max<int64_t>(4 * ctx->n_pairs, 1) * sizeof(double)));
+    }
+    const int npk = dim * (dim + 1) / 2;
+    HIPCHK(hipMalloc((void**)&ctx->d_cbar, (size_t)3 * g.n_c * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&ctx->d_fmat, std::max<size_t>((size_t)6 * npk * g.n_g, 1) * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&ctx->d_fvec, std::max<size_t>((size_t)7 * dim * g.n_g, 1) * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&ctx->d_partial, (size_t)RED_SLOTS * RED_BLOCKS * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&ctx->d_red, RED_SLOTS * sizeof(double)));
+    HIPCHK(hipMemset(ctx->d_red, 0, RED_SLOTS * sizeof(double)));
+    HIPCHK(hipHostMalloc((void**)&ctx->h_red, RED_SLOTS * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&ctx->d_y, RED_SLOTS * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&ctx->d_vbj, std::max<size_t>((size_t)16 * g.n_nodes_owned, 1) * sizeof(double)));
+    ctx->n_red_blocks = std::min(RED_BLOCKS, nblocks(ctx->n_dof_owned));
+    // free the big host arrays that are no longer needed (pattern kept for export)
+    std::vector<int32_t>().swap(g.contrib_cell);
+    std::vector<double>().swap(g.contrib_k);
+    return KNP_OK;
+}
+
+int knp_destroy(knp_ctx* ctx) {
+    if (!ctx) return KNP_OK;
+    (void)hipDeviceSynchronize();
+    for (auto& r : ctx->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    dev_free(ctx->d_cells); dev_free(ctx->d_cell_side); dev_free(ctx->d_coords);
+    dev_free(ctx->d_node_vertex); dev_free(ctx->d_node_side); dev_free(ctx->d_node_i); dev_free(ctx->d_node_e);
+    dev_free(ctx->d_pair_ptr); dev_free(ctx->d_pair_col); dev_free(ctx->d_pair_row);
+    dev_free(ctx->d_pair_M); dev_free(ctx->d_pair_K);
+    dev_free(ctx->d_contrib_ptr); dev_free(ctx->d_contrib_cell); dev_free(ctx->d_contrib_k);
+    dev_free(ctx->d_fv); dev_free(ctx->d_fmeas); dev_free(ctx->d_gamma_prog); dev_free(ctx->d_qp); dev_free(ctx->d_qw);
+    dev_free(ctx->d_gv_vertex); dev_free(ctx->d_gv_node_i); dev_free(ctx->d_gv_node_e); dev_free(ctx->d_node_gv);
+    dev_free(ctx->d_gptr); dev_free(ctx->d_gcol); dev_free(ctx->d_grow); dev_free(ctx->d_gq_i); dev_free(ctx->d_gq_e);
+    dev_free(ctx->d_gdiag); dev_free(ctx->d_gcptr); dev_free(ctx->d_gc_facet); dev_free(ctx->d_gc_lab);
+    dev_free(ctx->d_rowptr); dev_free(ctx->d_colind); dev_free(ctx->d_vals);
+    dev_free(ctx->d_p_rowptr); dev_free(ctx->d_p_colind); dev_free(ctx->d_p_vals);
+    dev_free(ctx->d_cbar); dev_free(ctx->d_fmat); dev_free(ctx->d_fvec);
+    dev_free(ctx->d_partial); dev_free(ctx->d_red); dev_free(ctx->d_y); dev_free(ctx->d_vbj);
+    if (ctx->h_red) (void)hipHostFree(ctx->h_red);
+    dev_free(ctx->d_V); dev_free(ctx->d_w); dev_free(ctx->d_t);
+    for (auto& p : ctx->progs) { dev_free(p.d_code); dev_free(p.d_consts); }
+    dev_free(ctx->d_prog_code); dev_free(ctx->d_prog_consts); dev_free(ctx->d_prog_len);
+    for (int l = 0; l < KNP_MAX_AMG_LEVELS; ++l) {
+        KnpAmgLevel& L = ctx->amg[l];
+        dev_free(L.A_rp); dev_free(L.A_ci); dev_free(L.A_v); dev_free(L.inv_diag);
+        dev_free(L.P_rp); dev_free(L.P_ci); dev_free(L.P_v); dev_free(L.R_rp); dev_free(L.R_ci); dev_free(L.R_v);
+        dev_free(L.x); dev_free(L.b); dev_free(L.r); dev_free(L.d);
+    }
+    dev_free(ctx->d_amg_cinv);
+    delete ctx;
+    return KNP_OK;
+}
+
+int knp_set_stream(knp_ctx* ctx, void* s) {
+    CHECK_CTX(ctx);
+    ctx->stream = (hipStream_t)s;
+    return KNP_OK;
+}
+int knp_set_comm(knp_ctx* ctx, knp_halo_fn halo, knp_allreduce_fn ar, void* user) {
+    CHECK_CTX(ctx);
+    ctx->halo = halo; ctx->allreduce = ar; ctx->comm_user = user;
+    return KNP_OK;
+}
+
+int knp_get_sizes(const knp_ctx* ctx, int64_t* s) {
+    if (!ctx || !s) return KNP_E_ARG;
+    for (int i = 0; i < KNP_SZ_COUNT; ++i) s[i] = 0;
+    s[KNP_SZ_N_NODES] = ctx->g.n_nodes;
+    s[KNP_SZ_N_NODES_OWNED] = ctx->g.n_nodes_owned;
+    s[KNP_SZ_N_DOF_LOCAL] = ctx->n_dof_local;
+    s[KNP_SZ_N_DOF_OWNED] = ctx->n_dof_owned;
+    s[KNP_SZ_NNZ] = ctx->nnz;
+    s[KNP_SZ_N_PAIRS] = ctx->n_pairs;
+    s[KNP_SZ_N_CONTRIB] = ctx->n_contrib;
+    s[KNP_SZ_N_GAMMA_VERTS] = ctx->g.n_gv;
+    s[KNP_SZ_N_GAMMA_PAIRS] = ctx->n_gp;
+    s[KNP_SZ_NNZ_P] = 4 * ctx->n_pairs;
+    s[KNP_SZ_N_PHI_OWNED] = ctx->g.n_nodes_owned;
+    return KNP_OK;
+}
+int knp_get_layout(const knp_ctx* ctx, int32_t* ni, int32_t* ne) {
+    if (!ctx || !ni || !ne) return KNP_E_ARG;
+    std::memcpy(ni, ctx->g.node_i.data(), ctx->g.node_i.size() * sizeof(int32_t));
+    std::memcpy(ne, ctx->g.node_e.data(), ctx->g.node_e.size() * sizeof(int32_t));
+    return KNP_OK;
+}
+int knp_get_csr_pattern(const knp_ctx* ctx, int32_t* rp, int32_t* ci) {
+    if (!ctx || !rp || !ci) return KNP_E_ARG;
+    std::memcpy(rp, ctx->g.rowptr.data(), ctx->g.rowptr.size() * sizeof(int32_t));
+    std::memcpy(ci, ctx->g.colind.data(), ctx->g.colind.size() * sizeof(int32_t));
+    return KNP_OK;
+}
+int knp_get_csr_values(const knp_ctx* cctx, double* vals) {
+    knp_ctx* ctx = const_cast<knp_ctx*>(cctx);
+    if (!ctx || !vals) return KNP_E_ARG;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(vals, ctx->d_vals, ctx->nnz * sizeof(double), hipMemcpyDeviceToHost));
+    return KNP_OK;
+}
+int knp_get_precond_csr(const knp_ctx* cctx, int32_t* rp, int32_t* ci, double* vals) {
+    knp_ctx* ctx = const_cast<knp_ctx*>(cctx);
+    if (!ctx || !rp || !ci || !vals) return KNP_E_ARG;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(rp, ctx->d_p_rowptr, ((size_t)ctx->n_dof_owned + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ci, ctx->d_p_colind, (size_t)4 * ctx->n_pairs * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(vals, ctx->d_p_vals, (size_t)4 * ctx->n_pairs * sizeof(double), hipMemcpyDeviceToHost));
+    return KNP_OK;
+}
+int knp_get_device_csr(const knp_ctx* ctx, const int32_t** rp, const int32_t** ci, const double** v) {
+    if (!ctx) return KNP_E_ARG;
+    if (rp) *rp = ctx->d_rowptr;
+    if (ci) *ci = ctx->d_colind;
+    if (v) *v = ctx->d_vals;
+    return KNP_OK;
+}
+
+int knp_set_params(knp_ctx* ctx, double dt, double F, double C_M, double psi, int32_t n_ions, const double* z,
+                   const double* Di, const double* De) {
+    CHECK_CTX(ctx);
+    if (n_ions != 3 || !z || !Di || !De) { ctx->err = "n_ions must be 3 (Na, K, Cl; KNPEMIx_problem.py:980-981)"; return KNP_E_ARG; }
+    if (!(dt > 0) || !(psi > 0) || F == 0.0) { ctx->err = "dt, psi must be positive and F non-zero"; return KNP_E_ARG; }
+    ctx->dt = dt; ctx->F = F; ctx->C_M = C_M; ctx->psi = psi; ctx->n_ions = 3;
+    for (int j = 0; j < 3; ++j) {
+        if (z[j] == 0.0 || !(Di[j] > 0) || !(De[j] > 0)) { ctx->err = "valence must be non-zero and diffusivities positive"; return KNP_E_ARG; }
+        ctx->z[j] = z[j]; ctx->Di[j] = Di[j]; ctx->De[j] = De[j];
+    }
+    return KNP_OK;
+}
+
+static int validate_program(knp_ctx* ctx, int n_instr, const int32_t* code, int n_consts) {
+    for (int i = 0; i < n_instr; ++i) {
+        const int op = code[4 * i], d = code[4 * i + 1], a = code[4 * i + 2], b = code[4 * i + 3];
+        auto regok = [](int r) { return r >= 0 && r < KNP_MAX_PROG_REGS; };
+        bool ok = true;
+        switch (op) {
+            case KNP_OP_CONST: ok = regok(d) && a >= 0 && a < n_consts; break;
+            case KNP_OP_KI: case KNP_OP_KE: ok = regok(d) && a >= 0 && a < 3; break;
+            case KNP_OP_PHIM: ok = regok(d); break;
+            case KNP_OP_AUX: ok = regok(d) && a >= 0 && a < KNP_MAX_AUX; break;
+            case KNP_OP_X: ok = regok(d) && a >= 0 && a < ctx->g.dim; break;
+            case KNP_OP_NEG: case KNP_OP_LN: case KNP_OP_EXP: case KNP_OP_SQRT: case KNP_OP_ABS: case KNP_OP_NOT:
+            case KNP_OP_MOV: case KNP_OP_POWI: ok = regok(d) && regok(a); break;
+            case KNP_OP_OUT: ok = a >= 0 && a < 3 && regok(b); break;
+            default: ok = (op >= KNP_OP_ADD && op <= KNP_OP_SEL) && regok(d) && regok(a) && regok(b); break;
+        }
+        if (!ok) { ctx->err = "invalid membrane program instruction " + std::to_string(i); return KNP_E_ARG; }
+    }
+    return KNP_OK;
+}
+
+int knp_set_program(knp_ctx* ctx, int32_t id, int32_t n_instr, const int32_t* code, int32_t n_consts, const double* consts) {
+    CHECK_CTX(ctx);
+    if (id < 0 || id > 4096 || n_instr < 0 || (n_instr && !code) || n_consts < 0 || (n_consts && !consts)) { ctx->err = "bad program arguments"; return KNP_E_ARG; }
+    KCHK(validate_program(ctx, n_instr, code, n_consts));
+    if ((int)ctx->progs.size() <= id) ctx->progs.resize(id + 1);
+    KnpProgram& p = ctx->progs[id];
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    dev_free(p.d_code); dev_free(p.d_consts);
+    p.n_instr = n_instr; p.n_consts = n_consts;
+    KCHK(dev_upload_raw(ctx, &p.d_code, code, (size_t)4 * n_instr));
+    KCHK(dev_upload_raw(ctx, &p.d_consts, consts, (size_t)n_consts));
+    ctx->progs_dirty = true;
+    return KNP_OK;
+}
+int knp_set_program_constants(knp_ctx* ctx, int32_t id, int32_t n_consts, const double* consts) {
+    CHECK_CTX(ctx);
+    if (id < 0 || id >= (int)ctx->progs.size() || n_consts != ctx->progs[id].n_consts) { ctx->err = "program id / constant count mismatch"; return KNP_E_ARG; }
+    if (n_consts) HIPCHK(hipMemcpyAsync(ctx->progs[id].d_consts, consts, n_consts * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // consts is a caller-owned pageable buffer
+    return KNP_OK;
+}
+static int sync_program_table(knp_ctx* ctx) {
+    if (!ctx->progs_dirty) return KNP_OK;
+    const size_t np = std::max<size_t>(ctx->progs.size(), 1);
+    std::vector<int32_t*> codes(np, nullptr);
+    std::vector<double*> consts(np, nullptr);
+    std::vector<int32_t> lens(np, 0);
+    for (size_t i = 0; i < ctx->progs.size(); ++i) { codes[i] = ctx->progs[i].d_code; consts[i] = ctx->progs[i].d_consts; lens[i] = ctx->progs[i].n_instr; }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    dev_free(ctx->d_prog_code); dev_free(ctx->d_prog_consts); dev_free(ctx->d_prog_len);
+    KCHK(dev_upload(ctx, &ctx->d_prog_code, codes));
+    KCHK(dev_upload(ctx, &ctx->d_prog_consts, consts));
+    KCHK(dev_upload(ctx, &ctx->d_prog_len, lens));
+    ctx->progs_dirty = false;
+    return KNP_OK;
+}
+
+int knp_set_sources(knp_ctx* ctx, const double* const* fi, const double* const* fe) {
+    CHECK_CTX(ctx);
+    ctx->have_sources = false;
+    for (int j = 0; j < 3; ++j) {
+        ctx->src_i[j] = fi ? fi[j] : nullptr;
+        ctx->src_e[j] = fe ? fe[j] : nullptr;
+        if (ctx->src_i[j] || ctx->src_e[j]) ctx->have_sources = true;
+    }
+    return KNP_OK;
+}
+
+static int check_fields(knp_ctx* ctx, const knp_fields* f, bool need_phim) {
+    if (!f) { ctx->err = "null fields"; return KNP_E_ARG; }
+    for (int j = 0; j < 3; ++j)
+        if (!f->k_i[j] || !f->k_e[j]) { ctx->err = "null concentration field"; return KNP_E_ARG; }
+    if (need_phim && !f->phi_m) { ctx->err = "null phi_m field"; return KNP_E_ARG; }
+    if (!(ctx->dt > 0)) { ctx->err = "knp_set_params has not been called"; return KNP_E_STATE; }
+    return KNP_OK;
+}
+
+int knp_assemble_matrix(knp_ctx* ctx, const knp_fields* fields) {
+    CHECK_CTX(ctx);
+    KCHK(check_fields(ctx, fields, false));
+    const KnpHostGraph& g = ctx->g;
+    const DevParams P = make_params(ctx);
+    FieldPtrs f = make_fields(fields);
+    ProfScope ps(ctx, 3);
+    hipLaunchKernelGGL(k_cell_means, dim3(nblocks(g.n_c)), dim3(NT), 0, ctx->stream, g.n_c, g.nv1, ctx->d_cells,
+                       ctx->d_cell_side, f, ctx->d_cbar);
+    if (ctx->n_pairs)
+        hipLaunchKernelGGL((k_assemble_pairs<false>), dim3(nblocks(ctx->n_pairs)), dim3(NT), 0, ctx->stream, ctx->n_pairs,
+                           g.n_c, P, ctx->d_pair_row, ctx->d_pair_ptr, ctx->d_node_side, ctx->d_pair_M, ctx->d_pair_K,
+                           ctx->d_contrib_ptr, ctx->d_contrib_cell, ctx->d_contrib_k, ctx->d_cbar, ctx->d_rowptr, ctx->d_vals);
+    if (g.n_g > 0) {
+        if (g.dim == 2)
+            hipLaunchKernelGGL((k_gamma_facets<2, true, false>), dim3(nblocks(g.n_g)), dim3(NT), 0, ctx->stream, g.n_g, g.n_q, P,
+                               ctx->d_fv, ctx->d_fmeas, ctx->d_qp, ctx->d_qw, f, 0, ctx->d_coords, ctx->d_gamma_prog,
+                               (const int32_t* const*)nullptr, (const int32_t*)nullptr, (const double* const*)nullptr,
+                               ctx->d_fmat, ctx->d_fvec);
+        else
+            hipLaunchKernelGGL((k_gamma_facets<3, true, false>), dim3(nblocks(g.n_g)), dim3(NT), 0, ctx->stream, g.n_g, g.n_q, P,
+                               ctx->d_fv, ctx->d_fmeas, ctx->d_qp, ctx->d_qw, f, 0, ctx->d_coords, ctx->d_gamma_prog,
+                               (const int32_t* const*)nullptr, (const int32_t*)nullptr, (const double* const*)nullptr,
+                               ctx->d_fmat, ctx->d_fvec);
+        if (ctx->n_gp)
+            hipLaunchKernelGGL((k_gamma_pairs<false>), dim3(nblocks(ctx->n_gp)), dim3(NT), 0, ctx->stream, ctx->n_gp, g.n_g, g.dim, P,
+                               ctx->d_grow, ctx->d_gptr, ctx->d_gv_node_i, ctx->d_gv_node_e, ctx->d_gq_i, ctx->d_gq_e,
+                               ctx->d_gcptr, ctx->d_gc_facet, ctx->d_gc_lab, ctx->d_fmeas, ctx->d_fmat, ctx->d_pair_ptr,
+                               ctx->d_rowptr, ctx->d_vals);
+    }
+    HIPCHK(hipGetLastError());
+    ctx->have_A = true;
+    if (ctx->pc_kind == KNP_PC_VBJACOBI) {
+        hipLaunchKernelGGL(k_vbj_extract, dim3(nblocks(g.n_nodes_owned)), dim3(NT), 0, ctx->stream, g.n_nodes_owned,
+                           ctx->d_pair_ptr, ctx->d_pair_col, ctx->d_rowptr, ctx->d_vals, ctx->d_node_gv, ctx->d_gptr,
+                           ctx->d_gdiag, ctx->d_vbj);
+        HIPCHK(hipGetLastError());
+    }
+    return KNP_OK;
+}
+
+int knp_assemble_precond(knp_ctx* ctx, const knp_fields* fields) {
+    CHECK_CTX(ctx);
+    KCHK(check_fields(ctx, fields, false));
+    const KnpHostGraph& g = ctx->g;
+    const DevParams P = make_params(ctx);
+    FieldPtrs f = make_fields(fields);
+    ProfScope ps(ctx, 3);
+    hipLaunchKernelGGL(k_cell_means, dim3(nblocks(g.n_c)), dim3(NT), 0, ctx->stream, g.n_c, g.nv1, ctx->d_cells,
+                       ctx->d_cell_side, f, ctx->d_cbar);
+    if (ctx->n_pairs)
+        hipLaunchKernelGGL((k_assemble_pairs<true>), dim3(nblocks(ctx->n_pairs)), dim3(NT), 0, ctx->stream, ctx->n_pairs,
+                           g.n_c, P, ctx->d_pair_row, ctx->d_pair_ptr, ctx->d_node_side, ctx->d_pair_M, ctx->d_pair_K,
+                           ctx->d_contrib_ptr, ctx->d_contrib_cell, ctx->d_contrib_k, ctx->d_cbar, ctx->d_rowptr, ctx->d_p_vals);
+    if (g.n_g > 0 && ctx->n_gp)
+        hipLaunchKernelGGL((k_gamma_pairs<true>), dim3(nblocks(ctx->n_gp)), dim3(NT), 0, ctx->stream, ctx->n_gp, g.n_g, g.dim, P,
+                           ctx->d_grow, ctx->d_gptr, ctx->d_gv_node_i, ctx->d_gv_node_e, ctx->d_gq_i, ctx->d_gq_e,
+                           ctx->d_gcptr, ctx->d_gc_facet, ctx->d_gc_lab, ctx->d_fmeas, ctx->d_fmat, ctx->d_pair_ptr,
+                           ctx->d_rowptr, ctx->d_p_vals);
+    HIPCHK(hipGetLastError());
+    ctx->have_P = true;
+    return KNP_OK;
+}
+
+int knp_assemble_rhs(knp_ctx* ctx, const knp_fields* fields, double* b) {
+    CHECK_CTX(ctx);
+    KCHK(check_fields(ctx, fields, true));
+    if (!b) { ctx->err = "null b"; return KNP_E_ARG; }
+    const KnpHostGraph& g = ctx->g;
+    const DevParams P = make_params(ctx);
+    FieldPtrs f = make_fields(fields);
+    int n_aux = 0;
+    for (int k = 0; k < KNP_MAX_AUX; ++k)
+        if (fields->aux[k]) n_aux = k + 1;
+    for (int k = 0; k < n_aux; ++k)
+        if (!fields->aux[k]) { ctx->err = "aux fields must be contiguous from index 0"; return KNP_E_ARG; }
+    if (g.n_g > 0) {
+        KCHK(sync_program_table(ctx));
+        // every facet's program must exist
+        if ((int)ctx->progs.size() <= ctx->max_prog) { ctx->err = "a membrane facet refers to a program that was not set (knp_set_program)"; return KNP_E_STATE; }
+        for (int i = 0; i <= ctx->max_prog; ++i)
+            if (!ctx->progs[i].d_code) { ctx->err = "membrane program " + std::to_string(i) + " not set"; return KNP_E_STATE; }
+    }
+    ProfScope ps(ctx, 3);
+    if (g.n_g > 0) {
+        if (g.dim == 2)
+            hipLaunchKernelGGL((k_gamma_facets<2, false, true>), dim3(nblocks(g.n_g)), dim3(NT), 0, ctx->stream, g.n_g, g.n_q, P,
+                               ctx->d_fv, ctx->d_fmeas, ctx->d_qp, ctx->d_qw, f, n_aux, ctx->d_coords, ctx->d_gamma_prog,
+                               (const int32_t* const*)ctx->d_prog_code, (const int32_t*)ctx->d_prog_len,
+                               (const double* const*)ctx->d_prog_consts, ctx->d_fmat, ctx->d_fvec);
+        else
+            hipLaunchKernelGGL((k_gamma_facets<3, false, true>), dim3(nblocks(g.n_g)), dim3(NT), 0, ctx->stream, g.n_g, g.n_q, P,
+                               ctx->d_fv, ctx->d_fmeas, ctx->d_qp, ctx->d_qw, f, n_aux, ctx->d_coords, ctx->d_gamma_prog,
+                               (const int32_t* const*)ctx->d_prog_code, (const int32_t*)ctx->d_prog_len,
+                               (const double* const*)ctx->d_prog_consts, ctx->d_fmat, ctx->d_fvec);
+    }
+    FieldPtrs src;
+    for (int j = 0; j < 3; ++j) { src.ki[j] = ctx->src_i[j]; src.ke[j] = ctx->src_e[j]; }
+    src.phim = nullptr;
+    for (int k = 0; k < KNP_MAX_AUX; ++k) src.aux[k] = nullptr;
+    hipLaunchKernelGGL(k_rhs, dim3(nblocks(g.n_nodes_owned)), dim3(NT), 0, ctx->stream, g.n_nodes_owned, g.n_g, g.dim, ctx->dt,
+                       ctx->d_node_vertex, ctx->d_node_side, ctx->d_pair_ptr, ctx->d_pair_col, ctx->d_pair_M, f, src,
+                       ctx->have_sources ? 1 : 0, ctx->d_node_gv, ctx->d_gdiag, ctx->d_gcptr, ctx->d_gc_facet, ctx->d_gc_lab,
+                       ctx->d_fvec, b);
+    HIPCHK(hipGetLastError());
+    return KNP_OK;
+}
+
+// ---- reductions: partial blocks -> d_red[slot], then (multi-GPU) all-reduce of a slot range ----
+static int allreduce_slots(knp_ctx* ctx, int slot0, int count) {
+    if (ctx->allreduce) {
+        int rc = ctx->allreduce(ctx->comm_user, ctx->d_red + slot0, count);
+        if (rc != 0) { ctx->err = "allreduce hook failed"; return KNP_E_STATE; }
+    }
+    return KNP_OK;
+}
+static int halo_update(knp_ctx* ctx, double* x) {
+    if (ctx->halo) {
+        int rc = ctx->halo(ctx->comm_user, x);
+        if (rc != 0) { ctx->err = "halo hook failed"; return KNP_E_STATE; }
+    }
+    return KNP_OK;
+}
+static int dot_to_slot(knp_ctx* ctx, const double* a, const double* b, int slot) {
+    const int nb = ctx->n_red_blocks;
+    hipLaunchKernelGGL(k_dot, dim3(nb), dim3(NT), 0, ctx->stream, ctx->n_dof_owned, a, b, ctx->d_partial);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(NT), 0, ctx->stream, nb, ctx->d_partial, ctx->d_red, slot);
+    return allreduce_slots(ctx, slot, 1);
+}
+static int read_slots(knp_ctx* ctx, int slot0, int count) {
+    HIPCHK(hipMemcpyAsync(ctx->h_red + slot0, ctx->d_red + slot0, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return KNP_OK;
+}
+
+static int64_t global_phi_count(knp_ctx* ctx, int* rc) {
+    // number of potential DoFs over all ranks (uses slot 63)
+    *rc = KNP_OK;
+    double v = (double)ctx->g.n_nodes_owned;
+    if (hipMemcpyAsync(ctx->d_red + 63, &v, sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { *rc = KNP_E_HIP; return 0; }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) { *rc = KNP_E_HIP; return 0; }
+    *rc = allreduce_slots(ctx, 63, 1);
+    if (*rc != KNP_OK) return 0;
+    *rc = read_slots(ctx, 63, 1);
+    return (int64_t)llround(ctx->h_red[63]);
+}
+
+int knp_set_nullspace(knp_ctx* ctx, int32_t on) {
+    CHECK_CTX(ctx);
+    ctx->ns_on = on ? 1 : 0;
+    return KNP_OK;
+}
+
+static int project_ns(knp_ctx* ctx, double* v) {
+    int rc;
+    const int64_t cnt = global_phi_count(ctx, &rc);
+    KCHK(rc);
+    if (cnt <= 0) return KNP_OK;
+    const int no = ctx->g.n_nodes_owned;
+    const int nb = std::min(RED_BLOCKS, nblocks(no));
+    hipLaunchKernelGGL(k_phi_sum, dim3(nb), dim3(NT), 0, ctx->stream, no, v, ctx->d_partial);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(NT), 0, ctx->stream, nb, ctx->d_partial, ctx->d_red, 62);
+    KCHK(allreduce_slots(ctx, 62, 1));
+    hipLaunchKernelGGL(k_phi_sub, dim3(nblocks(no)), dim3(NT), 0, ctx->stream, no, ctx->d_red + 62, 1.0 / (double)cnt, v);
+    HIPCHK(hipGetLastError());
+    return KNP_OK;
+}
+int knp_project_nullspace(knp_ctx* ctx, double* v) {
+    CHECK_CTX(ctx);
+    if (!v) return KNP_E_ARG;
+    return project_ns(ctx, v);
+}
+
+static int ensure_work(knp_ctx* ctx, int restart) {
+    if (!ctx->d_w) {
+        HIPCHK(hipMalloc((void**)&ctx->d_w, std::max(ctx->n_dof_local, 1) * sizeof(double)));
+        HIPCHK(hipMalloc((void**)&ctx->d_t, std::max(ctx->n_dof_local, 1) * sizeof(double)));
+        HIPCHK(hipMemset(ctx->d_w, 0, std::max(ctx->n_dof_local, 1) * sizeof(double)));
+        HIPCHK(hipMemset(ctx->d_t, 0, std::max(ctx->n_dof_local, 1) * sizeof(double)));
+    }
+    if (restart > 0 && (ctx->gm_restart < restart || !ctx->d_V)) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        dev_free(ctx->d_V);
+        size_t bytes = (size_t)(restart + 1) * std::max(ctx->n_dof_local, 1) * sizeof(double);
+        HIPCHK(hipMalloc((void**)&ctx->d_V, bytes));
+        HIPCHK(hipMemset(ctx->d_V, 0, bytes));
+        ctx->gm_restart = restart;
+    }
+    return KNP_OK;
+}
+
+static int spmv_A(knp_ctx* ctx, double* x, const double* b, double* y, bool residual) {
+    KCHK(halo_update(ctx, x));
+    ProfScope ps(ctx, 0);
+    const int lanes = pick_lanes(ctx->n_dof_owned ? (double)ctx->nnz / ctx->n_dof_owned : 1.0);
+    if (residual)
+        launch_spmv<1>(ctx->stream, lanes, ctx->n_dof_owned, ctx->d_rowptr, ctx->d_colind, ctx->d_vals, x, b, y);
+    else
+        launch_spmv<0>(ctx->stream, lanes, ctx->n_dof_owned, ctx->d_rowptr, ctx->d_colind, ctx->d_vals, x, b, y);
+    HIPCHK(hipGetLastError());
+    return KNP_OK;
+}
+
+int knp_spmv(knp_ctx* ctx, const double* x, double* y) {
+    CHECK_CTX(ctx);
+    if (!x || !y) return KNP_E_ARG;
+    if (!ctx->have_A) { ctx->err = "matrix not assembled"; return KNP_E_STATE; }
+    return spmv_A(ctx, const_cast<double*>(x), nullptr, y, false);
+}
+
+int knp_nullspace_test(knp_ctx* ctx, double* out_norm) {
+    CHECK_CTX(ctx);
+    if (!out_norm) return KNP_E_ARG;
+    if (!ctx->have_A) { ctx->err = "matrix not assembled"; return KNP_E_STATE; }
+    KCHK(ensure_work(ctx, 0));
+    int rc;
+    const int64_t cnt = global_phi_count(ctx, &rc);
+    KCHK(rc);
+    hipLaunchKernelGGL(k_fill_phi, dim3(nblocks(ctx->g.n_nodes)), dim3(NT), 0, ctx->stream, ctx->g.n_nodes,
+                       1.0 / std::sqrt((double)std::max<int64_t>(cnt, 1)), ctx->d_w);
+    KCHK(spmv_A(ctx, ctx->d_w, nullptr, ctx->d_t, false));
+    KCHK(dot_to_slot(ctx, ctx->d_t, ctx->d_t, 61));
+    KCHK(read_slots(ctx, 61, 1));
+    *out_norm = std::sqrt(ctx->h_red[61]);
+    return KNP_OK;
+}
+
+// ---- AMG ---------------------------------------------------------------------------------
+int knp_amg_reset(knp_ctx* ctx, int32_t n_levels, int32_t pre, int32_t post, int32_t cheby) {
+    CHECK_CTX(ctx);
+    if (n_levels < 1 || n_levels > KNP_MAX_AMG_LEVELS || pre < 0 || post < 0 || cheby < 1) { ctx->err = "bad AMG parameters"; return KNP_E_ARG; }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int l = 0; l < KNP_MAX_AMG_LEVELS; ++l) {
+        KnpAmgLevel& L = ctx->amg[l];
+        dev_free(L.A_rp); dev_free(L.A_ci); dev_free(L.A_v); dev_free(L.inv_diag);
+        dev_free(L.P_rp); dev_free(L.P_ci); dev_free(L.P_v); dev_free(L.R_rp); dev_free(L.R_ci); dev_free(L.R_v);
+        dev_free(L.x); dev_free(L.b); dev_free(L.r); dev_free(L.d);
+        L.n = L.n_coarse = 0;
+    }
+    dev_free(ctx->d_amg_cinv);
+    ctx->amg_nc = 0;
+    ctx->amg_levels = n_levels; ctx->amg_pre = pre; ctx->amg_post = post; ctx->amg_cheby = cheby;
+    return KNP_OK;
+}
+int knp_amg_set_level(knp_ctx* ctx, int32_t level, int32_t n_rows, int32_t n_cols_halo, const int32_t* A_rp,
+                      const int32_t* A_ci, const double* A_v, const double* inv_diag, double lambda_max, int32_t n_coarse,
+                      const int32_t* P_rp, const int32_t* P_ci, const double* P_v, const int32_t* R_rp, const int32_t* R_ci,
+                      const double* R_v) {
+    CHECK_CTX(ctx);
+    (void)n_cols_halo;
+    if (level < 0 || level >= ctx->amg_levels || n_rows <= 0 || !A_rp || !A_ci || !A_v || !inv_diag) { ctx->err = "bad AMG level arguments"; return KNP_E_ARG; }
+    if (level == 0 && n_rows != ctx->n_dof_owned) { ctx->err = "AMG level 0 must have n_dof_owned rows"; return KNP_E_ARG; }
+    KnpAmgLevel& L = ctx->amg[level];
+    const int64_t nnzA = A_rp[n_rows];
+    for (int64_t k = 0; k < nnzA; ++k)
+        if (A_ci[k] < 0 || A_ci[k] >= n_rows) { ctx->err = "AMG level matrix column out of range"; return KNP_E_ARG; }
+    L.n = n_rows; L.n_coarse = n_coarse; L.lambda_max = lambda_max;
+    KCHK(dev_upload_raw(ctx, &L.A_rp, A_rp, (size_t)n_rows + 1));
+    KCHK(dev_upload_raw(ctx, &L.A_ci, A_ci, (size_t)nnzA));
+    KCHK(dev_upload_raw(ctx, &L.A_v, A_v, (size_t)nnzA));
+    KCHK(dev_upload_raw(ctx, &L.inv_diag, inv_diag, (size_t)n_rows));
+    L.A_lanes = pick_lanes((double)nnzA / n_rows);
+    if (n_coarse > 0) {
+        if (!P_rp || !P_ci || !P_v || !R_rp || !R_ci || !R_v) { ctx->err = "AMG transfer operators missing"; return KNP_E_ARG; }
+        const int64_t nnzP = P_rp[n_rows], nnzR = R_rp[n_coarse];
+        for (int64_t k = 0; k < nnzP; ++k)
+            if (P_ci[k] < 0 || P_ci[k] >= n_coarse) { ctx->err = "AMG prolongator column out of range"; return KNP_E_ARG; }
+        for (int64_t k = 0; k < nnzR; ++k)
+            if (R_ci[k] < 0 || R_ci[k] >= n_rows) { ctx->err = "AMG restrictor column out of range"; return KNP_E_ARG; }
+        KCHK(dev_upload_raw(ctx, &L.P_rp, P_rp, (size_t)n_rows + 1));
+        KCHK(dev_upload_raw(ctx, &L.P_ci, P_ci, (size_t)nnzP));
+        KCHK(dev_upload_raw(ctx, &L.P_v, P_v, (size_t)nnzP));
+        KCHK(dev_upload_raw(ctx, &L.R_rp, R_rp, (size_t)n_coarse + 1));
+        KCHK(dev_upload_raw(ctx, &L.R_ci, R_ci, (size_t)nnzR));
+        KCHK(dev_upload_raw(ctx, &L.R_v, R_v, (size_t)nnzR));
+        L.P_lanes = pick_lanes((double)nnzP / n_rows);
+        L.R_lanes = pick_lanes((double)nnzR / n_coarse);
+    }
+    HIPCHK(hipMalloc((void**)&L.x, (size_t)n_rows * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&L.b, (size_t)n_rows * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&L.r, (size_t)n_rows * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&L.d, (size_t)n_rows * sizeof(double)));
+    HIPCHK(hipMemset(L.x, 0, (size_t)n_rows * sizeof(double)));
+    HIPCHK(hipMemset(L.d, 0, (size_t)n_rows * sizeof(double)));
+    return KNP_OK;
+}
+int knp_amg_set_coarse(knp_ctx* ctx, int32_t n, const double* inv) {
+    CHECK_CTX(ctx);
+    if (n <= 0 || !inv) return KNP_E_ARG;
+    dev_free(ctx->d_amg_cinv);
+    KCHK(dev_upload_raw(ctx, &ctx->d_amg_cinv, inv, (size_t)n * n));
+    ctx->amg_nc = n;
+    return KNP_OK;
+}
+
+// Chebyshev smoothing of A x = b on one level; zero_guess: x == 0 on entry
+static void amg_smooth(knp_ctx* ctx, KnpAmgLevel& L, const double* b, double* x, bool zero_guess) {
+    const double lmax = 1.1 * L.lambda_max, lmin = 0.1 * L.lambda_max;  // smoothing interval [0.1, 1.1] * lambda_max
+    const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
+    const double sigma = theta / delta;
+    double rho_old = 1.0 / sigma;
+    const int deg = ctx->amg_cheby;
+    hipStream_t st = ctx->stream;
+    const int nb = nblocks(L.n);
+    // step 0: d = Dinv (b - A x) / theta ; x += d
+    if (zero_guess) {
+        hipLaunchKernelGGL(k_diag_scale, dim3(std::min(nb, 2048)), dim3(NT), 0, st, L.n, 1.0 / theta, L.inv_diag, b, L.d);
+        hipLaunchKernelGGL(k_diag_scale, dim3(std::min(nb, 2048)), dim3(NT), 0, st, L.n, 1.0 / theta, L.inv_diag, b, x);
+    } else {
+        launch_cheby(st, L.A_lanes, L.n, L.A_rp, L.A_ci, L.A_v, L.inv_diag, b, x, 0.0, 1.0 / theta, L.d);
+        hipLaunchKernelGGL(k_axpy, dim3(std::min(nb, 2048)), dim3(NT), 0, st, L.n, 1.0, L.d, x);
+    }
+    for (int k = 1; k < deg; ++k) {
+        const double rho = 1.0 / (2.0 * sigma - rho_old);
+        launch_cheby(st, L.A_lanes, L.n, L.A_rp, L.A_ci, L.A_v, L.inv_diag, b, x, rho * rho_old, 2.0 * rho / delta, L.d);
+        hipLaunchKernelGGL(k_axpy, dim3(std::min(nb, 2048)), dim3(NT), 0, st, L.n, 1.0, L.d, x);
+        rho_old = rho;
+    }
+}
+
+static int amg_vcycle(knp_ctx* ctx, int l, const double* b, double* x) {
+    hipStream_t st = ctx->stream;
+    KnpAmgLevel& L = ctx->amg[l];
+    const bool last = (l == ctx->amg_levels - 1);
+    if (last && ctx->amg_nc > 0) {
+        hipLaunchKernelGGL(k_dense_matvec, dim3(nblocks((int64_t)ctx->amg_nc * 64)), dim3(NT), 0, st, ctx->amg_nc, ctx->d_amg_cinv, b, x);
+        return KNP_OK;
+    }
+    if (last) {  // no coarse inverse supplied: smooth only
+        amg_smooth(ctx, L, b, x, true);
+        for (int s = 1; s < ctx->amg_pre + ctx->amg_post; ++s) amg_smooth(ctx, L, b, x, false);
+        return KNP_OK;
+    }
+    KnpAmgLevel& C = ctx->amg[l + 1];
+    const int nc = L.n_coarse;
+    bool zero = true;
+    for (int s = 0; s < ctx->amg_pre; ++s) { amg_smooth(ctx, L, b, x, zero); zero = false; }
+    if (zero) hipLaunchKernelGGL(k_fill, dim3(std::min(nblocks(L.n), 2048)), dim3(NT), 0, st, L.n, 0.0, x);
+    // r = b - A x ; b_c = R r
+    launch_spmv<1>(st, L.A_lanes, L.n, L.A_rp, L.A_ci, L.A_v, x, b, L.r);
+    launch_spmv<0>(st, L.R_lanes, nc, L.R_rp, L.R_ci, L.R_v, L.r, nullptr, C.b);
+    KCHK(amg_vcycle(ctx, l + 1, C.b, C.x));
+    // x += P x_c   (r reused as temp)
+    launch_spmv<0>(st, L.P_lanes, L.n, L.P_rp, L.P_ci, L.P_v, C.x, nullptr, L.r);
+    hipLaunchKernelGGL(k_axpy, dim3(std::min(nblocks(L.n), 2048)), dim3(NT), 0, st, L.n, 1.0, L.r, x);
+    for (int s = 0; s < ctx->amg_post; ++s) amg_smooth(ctx, L, b, x, false);
+    return KNP_OK;
+}
+
+int knp_pc_setup(knp_ctx* ctx, int32_t kind) {
+    CHECK_CTX(ctx);
+    if (kind != KNP_PC_NONE && kind != KNP_PC_VBJACOBI && kind != KNP_PC_AMG) { ctx->err = "unknown pc kind"; return KNP_E_ARG; }
+    if (kind == KNP_PC_AMG) {
+        if (ctx->amg_levels < 1 || ctx->amg[0].n != ctx->n_dof_owned) { ctx->err = "AMG hierarchy not supplied"; return KNP_E_STATE; }
+        for (int l = 0; l < ctx->amg_levels - 1; ++l)
+            if (ctx->amg[l].n_coarse != ctx->amg[l + 1].n) { ctx->err = "AMG level sizes inconsistent"; return KNP_E_STATE; }
+        if (ctx->amg_nc > 0 && ctx->amg_nc != ctx->amg[ctx->amg_levels - 1].n) { ctx->err = "AMG coarse inverse size mismatch"; return KNP_E_STATE; }
+    }
+    ctx->pc_kind = kind;
+    if (kind == KNP_PC_VBJACOBI && ctx->have_A) {
+        const KnpHostGraph& g = ctx->g;
+        hipLaunchKernelGGL(k_vbj_extract, dim3(nblocks(g.n_nodes_owned)), dim3(NT), 0, ctx->stream, g.n_nodes_owned,
+                           ctx->d_pair_ptr, ctx->d_pair_col, ctx->d_rowptr, ctx->d_vals, ctx->d_node_gv, ctx->d_gptr,
+                           ctx->d_gdiag, ctx->d_vbj);
+        HIPCHK(hipGetLastError());
+    }
+    return KNP_OK;
+}
+
+// z = M^{-1} r, then (optionally) gauge projection.  cnt = global number of potential DoFs.
+static int pc_apply_proj(knp_ctx* ctx, const double* r, double* z, int64_t cnt) {
+    {
+        ProfScope ps(ctx, 2);
+        const KnpHostGraph& g = ctx->g;
+        switch (ctx->pc_kind) {
+            case KNP_PC_VBJACOBI:
+                if (!ctx->have_A) { ctx->err = "vertex-block Jacobi needs an assembled matrix"; return KNP_E_STATE; }
+                hipLaunchKernelGGL(k_vbj_apply, dim3(nblocks(g.n_nodes_owned)), dim3(NT), 0, ctx->stream, g.n_nodes_owned,
+                                   ctx->d_node_side, ctx->d_node_gv, ctx->d_gv_node_e, ctx->d_vbj, r, z);
+                break;
+            case KNP_PC_AMG:
+                KCHK(amg_vcycle(ctx, 0, r, z));
+                break;
+            default:
+                HIPCHK(hipMemcpyAsync(z, r, (size_t)ctx->n_dof_owned * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+                break;
+        }
+        HIPCHK(hipGetLastError());
+    }
+    if (ctx->ns_on && cnt > 0) {
+        ProfScope ps(ctx, 4);
+        const int no = ctx->g.n_nodes_owned;
+        const int nb = std::min(RED_BLOCKS, nblocks(no));
+        hipLaunchKernelGGL(k_phi_sum, dim3(nb), dim3(NT), 0, ctx->stream, no, z, ctx->d_partial);
+        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(NT), 0, ctx->stream, nb, ctx->d_partial, ctx->d_red, 62);
+        KCHK(allreduce_slots(ctx, 62, 1));
+        hipLaunchKernelGGL(k_phi_sub, dim3(nblocks(no)), dim3(NT), 0, ctx->stream, no, ctx->d_red + 62, 1.0 / (double)cnt, z);
+        HIPCHK(hipGetLastError());
+    }
+    return KNP_OK;
+}
+
+int knp_pc_apply(knp_ctx* ctx, const double* r, double* z) {
+    CHECK_CTX(ctx);
+    if (!r || !z) return KNP_E_ARG;
+    int rc;
+    const int64_t cnt = ctx->ns_on ? global_phi_count(ctx, &rc) : 0;
+    return pc_apply_proj(ctx, r, z, cnt);
+}
+
+// ---- GMRES(restart), left preconditioning, classical Gram-Schmidt (KSPGMRES semantics) ------
+int knp_gmres_solve(knp_ctx* ctx, const double* b, double* x, double rtol, double atol, int32_t max_it, int32_t restart,
+                    int32_t* its, double* rnorm, int32_t* reason) {
+    CHECK_CTX(ctx);
+    if (!b || !x || !its || !rnorm || !reason) return KNP_E_ARG;
+    if (!ctx->have_A) { ctx->err = "matrix not assembled"; return KNP_E_STATE; }
+    if (restart < 1 || restart > RED_SLOTS - 8 || max_it < 0) { ctx->err = "restart must be in [1,56]"; return KNP_E_ARG; }
+    KCHK(ensure_work(ctx, restart));
+    const int n = ctx->n_dof_owned;
+    const int64_t ldv = ctx->n_dof_local;
+    const int nb = ctx->n_red_blocks;
+    hipStream_t st = ctx->stream;
+    int rc;
+    const int64_t cnt = ctx->ns_on ? global_phi_count(ctx, &rc) : 0;
+    if (ctx->ns_on) KCHK(rc);
+    const int m = restart;
+    std::vector<double> H((size_t)(m + 1) * m, 0.0), g(m + 1, 0.0), cs(m, 0.0), sn(m, 0.0), y(m, 0.0);
+    auto Hx = [&](int i, int j) -> double& { return H[(size_t)i + (size_t)j * (m + 1)]; };
+
+    // ||M b|| for the relative tolerance (non-zero initial guess, preconditioned norm)
+    KCHK(pc_apply_proj(ctx, b, ctx->d_w, cnt));
+    KCHK(dot_to_slot(ctx, ctx->d_w, ctx->d_w, 60));
+    KCHK(read_slots(ctx, 60, 1));
+    const double bnorm = std::sqrt(ctx->h_red[60]);
+    if (!std::isfinite(bnorm)) { *its = 0; *rnorm = bnorm; *reason = KNP_DIVERGED_NANORINF; return KNP_OK; }
+    const double ttol = std::max(rtol * bnorm, atol);
+    const double dtol = 1e5;
+    int it = 0;
+    double res = 0.0, res0 = -1.0;
+    *reason = 0;
+    while (true) {
+        // r = M (b - A x)
+        KCHK(spmv_A(ctx, x, b, ctx->d_t, true));
+        KCHK(pc_apply_proj(ctx, ctx->d_t, ctx->d_w, cnt));
+        KCHK(dot_to_slot(ctx, ctx->d_w, ctx->d_w, 60));
+        KCHK(read_slots(ctx, 60, 1));
+        const double beta = std::sqrt(ctx->h_red[60]);
+        res = beta;
+        if (res0 < 0) res0 = beta;
+        if (!std::isfinite(beta)) { *reason = KNP_DIVERGED_NANORINF; break; }
+        if (beta <= ttol) { *reason = (beta <= atol) ? KNP_CONVERGED_ATOL : KNP_CONVERGED_RTOL; break; }
+        if (it >= max_it) { *reason = KNP_DIVERGED_ITS; break; }
+        hipLaunchKernelGGL(k_scale_rsqrt, dim3(std::min(nblocks(n), 2048)), dim3(NT), 0, st, n, ctx->d_w, ctx->d_red + 60, ctx->d_V);
+        std::fill(g.begin(), g.end(), 0.0);
+        g[0] = beta;
+        int jd = 0;
+        bool stop = false;
+        for (int j = 0; j < m; ++j) {
+            double* vj = ctx->d_V + (size_t)j * ldv;
+            KCHK(spmv_A(ctx, vj, nullptr, ctx->d_t, false));
+            KCHK(pc_apply_proj(ctx, ctx->d_t, ctx->d_w, cnt));
+            {
+                ProfScope ps(ctx, 1);
+                for (int i0 = 0; i0 <= j; i0 += 8)
+                    hipLaunchKernelGGL((k_multi_dot<8>), dim3(nb), dim3(NT), 0, st, n, ldv, i0, j + 1, ctx->d_V, ctx->d_w, ctx->d_partial);
+                hipLaunchKernelGGL(k_reduce_partials, dim3(j + 1), dim3(NT), 0, st, nb, ctx->d_partial, ctx->d_red, 0);
+                KCHK(allreduce_slots(ctx, 0, j + 1));
+                hipLaunchKernelGGL(k_update_norm, dim3(nb), dim3(NT), 0, st, n, ldv, j + 1, ctx->d_V, ctx->d_red, ctx->d_w, ctx->d_partial);
+                hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(NT), 0, st, nb, ctx->d_partial, ctx->d_red, j + 1);
+                KCHK(allreduce_slots(ctx, j + 1, 1));
+                if (j + 1 < m + 1)
+                    hipLaunchKernelGGL(k_scale_rsqrt, dim3(std::min(nblocks(n), 2048)), dim3(NT), 0, st, n, ctx->d_w, ctx->d_red + j + 1,
+                                       ctx->d_V + (size_t)(j + 1) * ldv);
+                HIPCHK(hipGetLastError());
+            }
+            KCHK(read_slots(ctx, 0, j + 2));
+            const double hn = std::sqrt(std::max(ctx->h_red[j + 1], 0.0));
+            for (int i = 0; i <= j; ++i) Hx(i, j) = ctx->h_red[i];
+            Hx(j + 1, j) = hn;
+            for (int i = 0; i < j; ++i) {
+                const double t = cs[i] * Hx(i, j) + sn[i] * Hx(i + 1, j);
+                Hx(i + 1, j) = -sn[i] * Hx(i, j) + cs[i] * Hx(i + 1, j);
+                Hx(i, j) = t;
+            }
+            const double den = std::hypot(Hx(j, j), Hx(j + 1, j));
+            if (!(den > 0.0) || !std::isfinite(den)) { *reason = KNP_DIVERGED_NANORINF; stop = true; jd = j; break; }
+            cs[j] = Hx(j, j) / den;
+            sn[j] = Hx(j + 1, j) / den;
+            Hx(j, j) = den;
+            Hx(j + 1, j) = 0.0;
+            g[j + 1] = -sn[j] * g[j];
+            g[j] = cs[j] * g[j];
+            ++it;
+            jd = j + 1;
+            res = std::fabs(g[j + 1]);
+            if (res <= ttol) { *reason = (res <= atol) ? KNP_CONVERGED_ATOL : KNP_CONVERGED_RTOL; stop = true; break; }
+            if (it >= max_it) { *reason = KNP_DIVERGED_ITS; stop = true; break; }
+            if (res > dtol * res0) { *reason = KNP_DIVERGED_DTOL; stop = true; break; }
+        }
+        if (jd > 0) {
+            for (int i = jd - 1; i >= 0; --i) {
+                double s = g[i];
+                for (int k = i + 1; k < jd; ++k) s -= Hx(i, k) * y[k];
+                y[i] = s / Hx(i, i);
+            }
+            for (int i = 0; i < jd; ++i) ctx->h_red[i] = y[i];
+            HIPCHK(hipMemcpyAsync(ctx->d_y, ctx->h_red, jd * sizeof(double), hipMemcpyHostToDevice, st));
+            {
+                ProfScope ps(ctx, 1);
+                hipLaunchKernelGGL(k_lincomb, dim3(std::min(nblocks(n), 2048)), dim3(NT), 0, st, n, ldv, jd, ctx->d_V, ctx->d_y, x);
+            }
+            HIPCHK(hipStreamSynchronize(st));  // h_red is reused by the next reduction read-back
+        }
+        if (stop) break;
+    }
+    *its = it;
+    *rnorm = res;
+    KCHK(halo_update(ctx, x));
+    HIPCHK(hipGetLastError());
+    return KNP_OK;
+}
+
+// ---- state transfer -------------------------------------------------------------------------
+static int out_ptrs(knp_ctx* ctx, const knp_fields_out* f, OutPtrs& o, bool need_phim) {
+    if (!f) { ctx->err = "null fields"; return KNP_E_ARG; }
+    for (int j = 0; j < 3; ++j) {
+        if (!f->k_i[j] || !f->k_e[j]) { ctx->err = "null concentration field"; return KNP_E_ARG; }
+        o.ki[j] = f->k_i[j]; o.ke[j] = f->k_e[j];
+    }
+    if (!f->phi_i || !f->phi_e || (need_phim && !f->phi_m)) { ctx->err = "null potential field"; return KNP_E_ARG; }
+    o.phi_i = f->phi_i; o.phi_e = f->phi_e; o.phi_m = f->phi_m;
+    return KNP_OK;
+}
+int knp_pack(knp_ctx* ctx, const knp_fields_out* f, double* x) {
+    CHECK_CTX(ctx);
+    if (!x) return KNP_E_ARG;
+    OutPtrs o;
+    KCHK(out_ptrs(ctx, f, o, false));
+    hipLaunchKernelGGL(k_pack, dim3(nblocks(ctx->g.n_nodes)), dim3(NT), 0, ctx->stream, ctx->g.n_nodes, ctx->d_node_vertex,
+                       ctx->d_node_side, o, x);
+    HIPCHK(hipGetLastError());
+    return KNP_OK;
+}
+int knp_unpack(knp_ctx* ctx, const double* x, const knp_fields_out* f) {
+    CHECK_CTX(ctx);
+    if (!x) return KNP_E_ARG;
+    OutPtrs o;
+    KCHK(out_ptrs(ctx, f, o, true));
+    KCHK(halo_update(ctx, const_cast<double*>(x)));
+    hipLaunchKernelGGL(k_unpack, dim3(nblocks(ctx->g.n_v)), dim3(NT), 0, ctx->stream, ctx->g.n_v, ctx->d_node_i, ctx->d_node_e, x, o);
+    HIPCHK(hipGetLastError());
+    return KNP_OK;
+}
+int knp_hh_update(knp_ctx* ctx, const double* phi_m, double* n, double* m, double* h, int32_t count, double dt, double phi_rest,
+                  int32_t rush_larsen, int32_t substeps) {
+    CHECK_CTX(ctx);
+    if (!phi_m || !n || !m || !h || count < 0 || substeps < 1 || !(dt > 0)) { ctx->err = "bad hh_update arguments"; return KNP_E_ARG; }
+    if (count == 0) return KNP_OK;
+    ProfScope ps(ctx, 4);
+    hipLaunchKernelGGL(k_hh_update, dim3(nblocks(count)), dim3(NT), 0, ctx->stream, count, phi_m, n, m, h, dt, phi_rest,
+                       rush_larsen, substeps);
+    HIPCHK(hipGetLastError());
+    return KNP_OK;
+}
+int knp_l2_norms(knp_ctx* ctx, const double* phi_i, const double* phi_e, double* out) {
+    CHECK_CTX(ctx);
+    if (!phi_i || !phi_e || !out) return KNP_E_ARG;
+    const KnpHostGraph& g = ctx->g;
+    const int nb = std::min(RED_BLOCKS, nblocks(g.n_c_owned));
+    if (g.dim == 2)
+        hipLaunchKernelGGL((k_l2<2>), dim3(nb), dim3(NT), 0, ctx->stream, g.n_c_owned, ctx->d_cells, ctx->d_cell_side, ctx->d_coords, phi_i, phi_e, ctx->d_partial);
+    else
+        hipLaunchKernelGGL((k_l2<3>), dim3(nb), dim3(NT), 0, ctx->stream, g.n_c_owned, ctx->d_cells, ctx->d_cell_side, ctx->d_coords, phi_i, phi_e, ctx->d_partial);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(2), dim3(NT), 0, ctx->stream, nb, ctx->d_partial, ctx->d_red, 58);
+    HIPCHK(hipGetLastError());
+    KCHK(read_slots(ctx, 58, 2));
+    out[0] = ctx->h_red[58];
+    out[1] = ctx->h_red[59];
+    return KNP_OK;
+}
+
+// ---- instrumentation --------------------------------------------------------------------------
+int knp_profile_enable(knp_ctx* ctx, int32_t on) {
+    CHECK_CTX(ctx);
+    KCHK(prof_collect(ctx));
+    ctx->prof_on = on ? 1 : 0;
+    return KNP_OK;
+}
+int knp_profile_get(knp_ctx* ctx, int32_t cls, double* ms, int64_t* launches) {
+    CHECK_CTX(ctx);
+    if (cls < 0 || cls >= KNP_NPROF || !ms || !launches) return KNP_E_ARG;
+    KCHK(prof_collect(ctx));
+    *ms = ctx->prof_ms[cls];
+    *launches = ctx->prof_n[cls];
+    return KNP_OK;
+}
+int knp_profile_reset(knp_ctx* ctx) {
+    CHECK_CTX(ctx);
+    KCHK(prof_collect(ctx));
+    for (int i = 0; i < KNP_NPROF; ++i) { ctx->prof_ms[i] = 0; ctx->prof_n[i] = 0; }
+    return KNP_OK;
+}
+
+}  // extern "C"

@@ -804,6 +804,53 @@ def pc_exact_lu():
     return factory
 
 
+def pc_amg_vcycle(levels, coarse_inv, pre=1, post=1, cheby_degree=2):
+    """NumPy restatement of the V-cycle the HIP library applies (knp_kernels.hip: amg_vcycle /
+    amg_smooth).  ``levels`` = list of objects with .A (csr), .dinv, .lambda_max, .P, .R; the
+    hierarchy itself is *data* produced by the host setup and is passed in by the test.
+    Smoother: Chebyshev of the given degree on D^-1 A over [0.1, 1.1]*lambda_max."""
+    def smooth(lv, b, x, zero):
+        lmax, lmin = 1.1 * lv.lambda_max, 0.1 * lv.lambda_max
+        theta, delta = 0.5 * (lmax + lmin), 0.5 * (lmax - lmin)
+        sigma = theta / delta
+        rho_old = 1.0 / sigma
+        if zero:
+            d = lv.dinv * b / theta
+            x = d.copy()
+        else:
+            d = lv.dinv * (b - lv.A @ x) / theta
+            x = x + d
+        for _ in range(1, cheby_degree):
+            rho = 1.0 / (2.0 * sigma - rho_old)
+            d = rho * rho_old * d + (2.0 * rho / delta) * (lv.dinv * (b - lv.A @ x))
+            x = x + d
+            rho_old = rho
+        return x
+
+    def cycle(l, b):
+        lv = levels[l]
+        if l == len(levels) - 1:
+            if coarse_inv is not None:
+                return coarse_inv @ b
+            x = smooth(lv, b, None, True)
+            for _ in range(1, pre + post):
+                x = smooth(lv, b, x, False)
+            return x
+        x = None
+        for s in range(pre):
+            x = smooth(lv, b, x, x is None)
+        if x is None:
+            x = np.zeros_like(b)
+        r = b - lv.A @ x
+        xc = cycle(l + 1, lv.R @ r)
+        x = x + lv.P @ xc
+        for s in range(post):
+            x = smooth(lv, b, x, False)
+        return x
+
+    return lambda r: cycle(0, r)
+
+
 # --------------------------------------------------------------------------------------
 # Convenience constructors for the BASELINE configs
 # --------------------------------------------------------------------------------------

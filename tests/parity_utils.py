@@ -1,0 +1,83 @@
+"""Shared helpers of the parity tests: the CI physics as a config dict for the native path and as
+an oracle instance (test infrastructure; the oracle is only ever the checker)."""
+from __future__ import annotations
+
+import copy
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "knp-emi-cgx_amd"), os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+# physics of reference src/CGx/KNPEMI/configs/tests/electric_potential_norms_iterative_solver.yaml
+CI_BASE = {
+    "problem_type": "KNP-EMI",
+    "quiet": True,
+    "dt": 0.000025,
+    "time_steps": 10,
+    "physical_constants": {"T": 300, "F": 96485, "R": 8.314},
+    "C_M": 0.02,
+    "cell_tag_file": "square32.xdmf",
+    "facet_tag_file": "square32_facets.xdmf",
+    "ics_tags": [1], "ecs_tags": [2], "boundary_tags": [3], "membrane_tags": [4],
+    "mesh_conversion_factor": 1e-6,
+    "initial_conditions": {"phi_m": -0.070, "Na_i": 12, "Na_e": 140, "K_i": 130, "K_e": 4, "Cl_i": 5, "Cl_e": 125,
+                           "n": 0.276, "m": 0.0379, "h": 0.688},
+    "stimulus": {"conductance": {"g_syn_bar": 1e-9}, "a_syn": 5e-4, "T_stim": 1.0, "scale": True},
+    "solver": {"direct": False,
+               "ksp_settings": {"strong_threshold": 0.5, "ksp_rtol": 1e-9, "ksp_type": "gmres", "pc_type": "hypre",
+                                "norm_type": "preconditioned", "non_zero_init_guess": True},
+               "output": {"save_xdmf": False, "save_cpoints": False, "save_pngs": False, "save_dat": False}},
+}
+
+
+def ci_config(N=32, steps=10, rtol=1e-9, pc="hypre", kind="square", direct=False):
+    cfg = copy.deepcopy(CI_BASE)
+    cfg["time_steps"] = steps
+    cfg["cell_tag_file"] = f"{kind}{N}.xdmf"
+    cfg["facet_tag_file"] = f"{kind}{N}_facets.xdmf"
+    cfg["solver"]["direct"] = direct
+    cfg["solver"]["ksp_settings"]["ksp_rtol"] = rtol
+    cfg["solver"]["ksp_settings"]["pc_type"] = pc
+    return cfg
+
+
+def make_problem(cfg, models="ci", local_mesh=None):
+    """Construction order of the reference's test scripts (tests/KNPEMI/electric_potential_norms_*.py:27-36)."""
+    from CGx.KNPEMI.KNPEMIx_ionic_model import ATPPump, HodgkinHuxley, NeuronalCotransporters, PassiveModel
+    from CGx.KNPEMI.KNPEMIx_problem import ProblemKNPEMI
+    problem = ProblemKNPEMI(cfg, local_mesh=local_mesh)
+    if models == "ci":
+        ionic_models = [NeuronalCotransporters(problem), HodgkinHuxley(problem), ATPPump(problem)]
+    elif models == "passive":
+        ionic_models = [PassiveModel(problem)]
+    else:
+        ionic_models = models(problem)
+    problem.set_initial_conditions()
+    problem.init_ionic_models(ionic_models)
+    problem.setup_variational_form()
+    return problem
+
+
+def run_native(cfg, models="ci", local_mesh=None):
+    from CGx.KNPEMI.KNPEMIx_solver import SolverKNPEMI
+    problem = make_problem(cfg, models, local_mesh)
+    problem.solver_config["view_ksp"] = False
+    solver = SolverKNPEMI(problem, solver_config=problem.solver_config)
+    solver.solve()
+    return solver
+
+
+def make_oracle(N=32, kind="square", models="ci"):
+    import knpemi_oracle as K
+    mk = K.make_square if kind == "square" else K.make_cube
+    mdl = K.CI_MODELS() if models == "ci" else [K.Model("passive", (4,))]
+    return mk(N, models=mdl)
+
+
+def run_oracle(N=32, steps=10, kind="square", models="ci", solver="lu_gauge"):
+    o = make_oracle(N, kind, models)
+    o.run(steps, solver=solver)
+    return o

@@ -1,0 +1,187 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Tolerances (fp64 everywhere): assembled operators and vectors 1e-12 relative to the largest entry;
+solutions after time stepping 1e-6 relative on the potential norms / membrane potential
+(BASELINE.json: "matching reference potentials to rtol 1e-6").
+"""
+import numpy as np
+import pytest
+import torch
+
+from parity_utils import ci_config, make_oracle, make_problem, run_native, run_oracle
+
+pytestmark = pytest.mark.gpu
+
+PIN_ITERATIVE = (3.510994056704844e-08, 6.369472309249516e-11)   # reference tests/KNPEMI/electric_potential_norms_iterative_solver.py:58-59
+
+
+def _rel(a, b):
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+def _setup(N, kind, models="ci", perturb=True):
+    cfg = ci_config(N=N, steps=1, kind=kind)
+    p = make_problem(cfg, models=models)
+    be = p.create_backend()
+    o = make_oracle(N, kind, models)
+    if perturb:
+        # non-uniform but smooth previous state so that every term of the forms is exercised
+        X = o.coords / o.coords.max()
+        s = 1.0 + 0.05 * np.sin(3.0 * X[:, 0] + 1.0) * np.cos(2.0 * X[:, 1] + 0.5)
+        for side in range(2):
+            for j in range(3):
+                o.k[side][j] = o.k[side][j] * (s if (side + j) % 2 == 0 else 2.0 - s)
+                p.wh[side][j].x.array[:] = torch.as_tensor(o.k[side][j], device=p.mesh.device)
+        o.phi_m = o.phi_m * (2.0 - s)
+        p.phi_m_prev.x.array[:] = torch.as_tensor(o.phi_m, device=p.mesh.device)
+        for name in ("n", "m", "h"):
+            if hasattr(p, name):
+                setattr(o, name, getattr(o, name) * s)
+                getattr(p, name).x.array[:] = torch.as_tensor(getattr(o, name), device=p.mesh.device)
+    return p, be, o
+
+
+@pytest.mark.parametrize("N,kind", [(8, "square"), (12, "square"), (4, "cube")])
+def test_layout_and_pattern(N, kind):
+    p, be, o = _setup(N, kind, perturb=False)
+    assert be.n_dof_owned == o.n_dof
+    assert np.array_equal(be.node_i, o.lay.node_i.astype(np.int32))
+    assert np.array_equal(be.node_e, o.lay.node_e.astype(np.int32))
+
+
+@pytest.mark.parametrize("N,kind", [(8, "square"), (16, "square"), (4, "cube"), (8, "cube")])
+def test_matrix_rhs_precond_match_oracle(N, kind):
+    p, be, o = _setup(N, kind)
+    o.t = o.p.dt
+    o.update_t_mod()
+    p.t.value = o.p.dt
+    for m in p.ionic_models:
+        if hasattr(m, "update_t_mod"):
+            m.update_t_mod()
+    be.assemble_matrix()
+    A = be.csr()
+    Ao = o.assemble_A()
+    assert A.shape == Ao.shape
+    D = (A - Ao).tocoo()
+    assert (np.abs(D.data).max() if D.nnz else 0.0) <= 1e-12 * np.abs(Ao.data).max()
+    # structural pattern identical (explicit zeros kept on both sides are allowed to differ)
+    be.assemble_rhs()
+    b = be.b.cpu().numpy()
+    bo = o.assemble_b()
+    assert _rel(b, bo) <= 1e-12
+    # each block row separately (potential rows are 1e6 smaller than concentration rows)
+    for f in range(4):
+        assert _rel(b[f::4], bo[f::4]) <= 1e-10, f
+    be.assemble_precond()
+    P = be.precond_csr()
+    Po = o.assemble_P()
+    D = (P - Po).tocoo()
+    assert (np.abs(D.data).max() if D.nnz else 0.0) <= 1e-12 * np.abs(Po.data).max()
+
+
+@pytest.mark.parametrize("N,kind", [(16, "square"), (6, "cube")])
+def test_spmv_and_nullspace(N, kind):
+    p, be, o = _setup(N, kind)
+    be.assemble_matrix()
+    Ao = o.assemble_A()
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(o.n_dof)
+    xt = torch.as_tensor(x, device=be.device)
+    yt = torch.empty_like(xt)
+    be.spmv(xt, yt)
+    y = yt.cpu().numpy()
+    yo = Ao @ x
+    assert _rel(y, yo) <= 1e-13
+    assert be.nullspace_test() <= 1e-10 * np.abs(Ao.data).max()
+    # projection removes the mean of the potential entries only
+    v = torch.as_tensor(x.copy(), device=be.device)
+    be.project_nullspace(v)
+    ns = o.nullspace()
+    vo = x - ns * (ns @ x)
+    assert _rel(v.cpu().numpy(), vo) <= 1e-13
+
+
+def test_hh_gating_update_matches_oracle():
+    import knpemi_oracle as K
+    p, be, o = _setup(8, "square")
+    mdl = [m for m in o.models if m.kind == "hh"][0]
+    o.update_gating(mdl)
+    hh = [m for m in p.ionic_models if hasattr(m, "update_gating_variables")][0]
+    hh.update_gating_variables()
+    for name in ("n", "m", "h"):
+        assert _rel(getattr(p, name).numpy(), getattr(o, name)) <= 1e-12, name
+    # forward-Euler variant
+    hh.use_Rush_Larsen = False
+    mdl.use_rush_larsen = False
+    o.update_gating(mdl)
+    hh.update_gating_variables()
+    for name in ("n", "m", "h"):
+        assert _rel(getattr(p, name).numpy(), getattr(o, name)) <= 1e-12, name
+
+
+def test_pc_apply_vbjacobi_inverts_vertex_blocks():
+    p, be, o = _setup(8, "square")
+    be.assemble_matrix()
+    be.pc_setup(1)
+    A = be.csr().tocsr()
+    rng = np.random.default_rng(1)
+    r = rng.standard_normal(o.n_dof)
+    rt = torch.as_tensor(r, device=be.device)
+    zt = torch.zeros_like(rt)
+    be.pc_apply(rt, zt)
+    z = zt.cpu().numpy()
+    grp = o.lay.node_vertex
+    starts = np.nonzero(np.r_[True, grp[1:] != grp[:-1]])[0]
+    sizes = np.diff(np.r_[starts, o.lay.n_nodes])
+    for s, sz in zip(starts, sizes):
+        idx = np.arange(4 * s, 4 * (s + sz))
+        blk = A[idx][:, idx].toarray()
+        assert np.allclose(blk @ z[idx], r[idx], rtol=1e-9, atol=1e-12 * np.abs(r).max())
+
+
+@pytest.mark.parametrize("pc", ["hypre", "vbjacobi"])
+def test_two_steps_match_oracle(pc):
+    cfg = ci_config(N=16, steps=2, rtol=1e-13 if pc == "hypre" else 1e-14, pc=pc)
+    cfg["solver"]["ksp_settings"]["ksp_max_it"] = 20000
+    s = run_native(cfg)
+    o = run_oracle(N=16, steps=2)
+    ni, ne = s.potential_norms()
+    oi, oe = o.potential_norms()
+    assert abs(ni - oi) <= 1e-6 * oi
+    phim = s.problem.phi_m_prev.numpy()
+    gam = (o.lay.node_i >= 0) & (o.lay.node_e >= 0)
+    assert np.allclose(phim[gam], o.phi_m[gam], rtol=1e-6)
+    for j in range(3):
+        vi = o.lay.node_i >= 0
+        ve = o.lay.node_e >= 0
+        assert np.allclose(s.problem.wh[0][j].numpy()[vi], o.k[0][j][vi], rtol=1e-9)
+        assert np.allclose(s.problem.wh[1][j].numpy()[ve], o.k[1][j][ve], rtol=1e-9)
+    if pc == "hypre":
+        assert abs(ne - oe) <= 1e-4 * oe
+
+
+def test_ci_problem_against_reference_pins():
+    """The reference's own CI problem (32x32, 10 steps, GMRES rtol 1e-9, AMG in place of BoomerAMG)."""
+    s = run_native(ci_config(N=32, steps=10, rtol=1e-9))
+    ni, ne = s.potential_norms()
+    # phi_i: within the north-star tolerance of the reference's saved value
+    assert abs(ni - PIN_ITERATIVE[0]) <= 1e-6 * PIN_ITERATIVE[0]
+    # phi_e is 1000x smaller and only determined up to the linear-solver truncation error of the
+    # reference run itself (see tests/test_oracle_pins.py::test_iterative_pin_noise_floor)
+    assert abs(ne - PIN_ITERATIVE[1]) <= 3e-4 * PIN_ITERATIVE[1]
+    # iteration count comparable to the reference's 3.0 (hypre) -- informational bound
+    assert np.mean(s.iterations) <= 6.0
+    # gauge: sum of potential dofs conserved
+    x = s.backend.x.cpu().numpy()
+    assert abs(x[3::4].sum() - (-0.07 * 289)) <= 1e-9 * 0.07 * 289
+
+
+def test_cube_run_matches_oracle():
+    cfg = ci_config(N=8, steps=2, rtol=1e-13, kind="cube")
+    s = run_native(cfg)
+    o = run_oracle(N=8, steps=2, kind="cube")
+    ni, ne = s.potential_norms()
+    oi, oe = o.potential_norms()
+    assert abs(ni - oi) <= 1e-6 * oi
+    gam = (o.lay.node_i >= 0) & (o.lay.node_e >= 0)
+    assert np.allclose(s.problem.phi_m_prev.numpy()[gam], o.phi_m[gam], rtol=1e-6)
