@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- MDoF/s per implicit KNP-EMI timestep (assembly + GMRES) on N MI355X GPUs of one node.
+
+One "step" = one implicit timestep of the reference's loop (src/CGx/KNPEMI/KNPEMIx_solver.py:365-468):
+Hodgkin-Huxley gating update, assembly of A and b, GMRES(30) solve with the AMG-on-block-diagonal-P
+preconditioner (the native counterpart of the reference's BoomerAMG-on-P), unpack + phi_m update.
+
+Workload (synthetic, deterministic, no RNG): BASELINE.json configs[1] -- the 512x512 unit square with the
+inner square [0.25,0.75]^2 as one cell, 3 ions, the CI physics of the reference's test YAML
+(HH + ATP pump + neuronal cotransporters), mesh scaled to micrometres, dt 25 us, rtol 1e-9.  With N GPUs the
+domain is N such unit squares stacked along y (one per rank, weak scaling, fixed work per GPU) with
+ghost-layer halo exchange and Krylov all-reduces over RCCL.  ``--workload cubeM`` selects the 3D analogue.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the byte model of `roofline`).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, "knp-emi-cgx_amd"), os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", type=str, default="square512", help="square<N> or cube<N> (per-GPU mesh)")
+    ap.add_argument("--pc", type=str, default="hypre", help="hypre(=native AMG on P) | vbjacobi | none")
+    ap.add_argument("--rtol", type=float, default=1e-9)
+    ap.add_argument("--models", type=str, default="ci", help="ci (HH+ATP+cotransporters) | passive")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--profile-all", action="store_true", help="time every kernel class with HIP events (adds overhead)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=os.environ.get("KNP_DIST_BACKEND", "nccl"), rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank) if os.environ.get("KNP_DIST_BACKEND", "nccl") == "nccl" else None)
+    else:
+        torch.cuda.set_device(0)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import re
+    from parity_utils import ci_config, make_problem
+    from cgx_hip import _lib
+    from cgx_hip.parallel import stacked_cubes_local_mesh, stacked_squares_local_mesh
+    from CGx.KNPEMI.KNPEMIx_solver import SolverKNPEMI
+
+    m = re.fullmatch(r"(square|cube)(\d+)", args.workload)
+    assert m, "workload must be square<N> or cube<N>"
+    kind, N = m.group(1), int(m.group(2))
+    gen = stacked_squares_local_mesh if kind == "square" else stacked_cubes_local_mesh
+    lm = gen(N, world, rank, scale=1e-6)
+
+    total_steps = args.warmup + args.steps
+    cfg = ci_config(N=N, steps=total_steps, rtol=args.rtol, pc=args.pc, kind=kind)
+    problem = make_problem(cfg, models=args.models, local_mesh=lm)
+    problem.solver_config["view_ksp"] = False
+    solver = SolverKNPEMI(problem, solver_config=problem.solver_config)
+
+    # ---- run the reference loop, but split into warmup and timed parts -------------------------
+    from cgx_hip.ionic_models import HodgkinHuxley
+    solver.setup_solver()
+    be = solver.backend
+    if solver._pc_kind == _lib.PC_AMG:
+        problem.setup_preconditioner(solver.use_block_Jacobi)
+        solver.assemble_preconditioner()
+    be.pc_setup(solver._pc_kind)
+
+    def one_step(i):
+        problem.t.value += float(problem.dt.value)
+        if problem.gating_variables:
+            for model in problem.ionic_models:
+                if isinstance(model, HodgkinHuxley):
+                    model.update_t_mod()
+                    model.update_gating_variables()
+        be.assemble_matrix()
+        be.assemble_rhs()
+        if i == 1:
+            solver.create_and_set_nullspace()
+        its, rnorm, reason = be.gmres(solver._rtol, 1e-50, solver.ksp_max_it, solver.gmres_restart)
+        be.unpack()
+        return its, reason
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    step_no = 0
+    its_all, reasons = [], []
+    for _ in range(args.warmup):
+        step_no += 1
+        it, rs = one_step(step_no)
+    if args.warmup == 0:
+        pass
+    be.profile_reset()
+    be.profile_enable(0x1f if args.profile_all else 0x1)       # class 0 = SpMV on A (dominant kernel)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step_no += 1
+        it, rs = one_step(step_no)
+        its_all.append(it)
+        reasons.append(rs)
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = be.profile_get()
+    be.profile_enable(0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    n_dof = be.n_dof_global
+    ms_per_step = 1e3 * elapsed / max(args.steps, 1)
+    value = n_dof * args.steps / elapsed / 1e6
+
+    # ---- roofline of the dominant kernel (CSR SpMV on A), per launch, this rank ---------------
+    spmv_ms, spmv_n = prof["spmv"]
+    b_spmv = 12.0 * be.nnz + 4.0 * (be.n_dof_owned + 1) + 8.0 * be.n_dof_owned + 8.0 * be.n_dof_local
+    roof = None
+    if spmv_n > 0 and spmv_ms > 0:
+        avg_s = spmv_ms * 1e-3 / spmv_n
+        ach = b_spmv / avg_s / 1e9
+        roof = {"bound": "hbm", "kernel": "k_spmv (CSR SpMV on A)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": b_spmv,
+                "avg_launch_us": avg_s * 1e6, "launches": int(spmv_n)}
+
+    norms = solver.potential_norms()
+
+    # ---- CPU baseline: the oracle (NumPy/SciPy restatement, 1 core) on a bounded sample --------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(kind, N, args.models, args.rtol, args.cpu_steps)
+
+    if rank == 0:
+        out = {
+            "metric": "MDoF/s per implicit timestep (assembly+GMRES)",
+            "value": value, "unit": "MDoF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{world} x unit {kind} {N}^{2 if kind == 'square' else 3} (BASELINE configs[{1 if kind == 'square' else 2}]), "
+                                   f"3 ions, HH+ATP+cotransporters, GMRES(30)+AMG on block-diagonal P, rtol {args.rtol:g}",
+                       "n_dof": int(n_dof), "nnz": int(be.nnz_global), "mechanisms": args.models, "pc": args.pc,
+                       "parallelism": f"dd{world}", "gmres_its_per_step": float(sum(its_all)) / max(len(its_all), 1),
+                       "converged_all": bool(all(r > 0 for r in reasons)),
+                       "phi_norms": [norms[0], norms[1]]},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+            "kernel_classes_ms": {k: {"ms": v[0], "launches": v[1]} for k, v in prof.items()} if args.profile_all else None,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(kind, N, models, rtol, steps):
+    """Oracle timed on the host: same mesh, same physics, same algorithm class (GMRES(30), left PC,
+    the same AMG hierarchy construction applied by the NumPy V-cycle), single thread."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import knpemi_oracle as K
+    from cgx_hip import amg
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    mk = K.make_square if kind == "square" else K.make_cube
+    mdl = K.CI_MODELS() if models == "ci" else [K.Model("passive", (4,))]
+    o = mk(N, models=mdl)
+
+    def fac(P):
+        h = amg.build_hierarchy(P)
+        return K.pc_amg_vcycle(h.levels, h.coarse_inv, 1, 1, 2)
+    times = []
+
+    def log(step, oo, x):
+        times.append(time.perf_counter())
+    # setup (P, hierarchy) excluded like on the GPU side: run() builds it before the loop
+    t_start = time.perf_counter()
+    o.run(steps + 1, solver="gmres", pc=fac, rtol=rtol, log=log)
+    # per-step time from step 2 on (step 1 includes the null-space check)
+    per = [(times[i] - times[i - 1]) for i in range(1, len(times))]
+    sec = sum(per) / len(per)
+    return {"value": o.n_dof / sec / 1e6, "unit": "MDoF/s", "cores": 1, "kind": "port",
+            "sample": f"{steps} implicit steps of the same {kind}{N} workload (NumPy/SciPy oracle, GMRES+AMG V-cycle in NumPy), "
+                      f"{sec:.2f} s/step; total {time.perf_counter() - t_start:.1f} s incl. setup"}
+
+
+if __name__ == "__main__":
+    main()

@@ -198,7 +198,7 @@ int knp_l2_norms(knp_ctx* ctx, const double* phi_i, const double* phi_e, double*
 /* ---- instrumentation ---- */
 /* elapsed ms and launch count of a kernel class since the last reset (HIP events on the ctx stream).
  * classes: 0 spmv, 1 orthogonalisation, 2 pc, 3 assembly, 4 other */
-int knp_profile_enable(knp_ctx* ctx, int32_t on);
+int knp_profile_enable(knp_ctx* ctx, int32_t class_mask); /* bit k enables class k; 0 disables */
 int knp_profile_get(knp_ctx* ctx, int32_t cls, double* ms, int64_t* launches);
 int knp_profile_reset(knp_ctx* ctx);
 

@@ -232,6 +232,14 @@ class Backend:
                                             C.byref(rn), C.byref(reason)))
         return its.value, rn.value, reason.value
 
+    def matrix_max_abs(self) -> float:
+        """max |A_ij| over the locally stored entries (views the library-owned value array in place)."""
+        vals = C.c_void_p()
+        self.check(self.lib.knp_get_device_csr(self.ctx, None, None, C.byref(vals)))
+        if self.nnz == 0:
+            return 0.0
+        return float(self._view(vals.value, self.nnz).abs().max().item())
+
     def l2_norms_sq(self):
         out = (C.c_double * 2)()
         p = self.p
@@ -266,8 +274,8 @@ class Backend:
         return P
 
     # ---- instrumentation -----------------------------------------------------------------
-    def profile_enable(self, on=True):
-        self.check(self.lib.knp_profile_enable(self.ctx, 1 if on else 0))
+    def profile_enable(self, mask=0x1f):
+        self.check(self.lib.knp_profile_enable(self.ctx, int(mask)))
 
     def profile_reset(self):
         self.check(self.lib.knp_profile_reset(self.ctx))

@@ -179,6 +179,42 @@ def stacked_cubes_local_mesh(N, size, rank, scale=1.0) -> LocalMesh:
     return lm
 
 
+def stacked_squares_local_mesh(N, size, rank, scale=1.0) -> LocalMesh:
+    """2D analogue of ``stacked_cubes_local_mesh``: ``size`` unit squares stacked along y, each with the
+    inner square [0.25,0.75]^2 (reference src/CGx/utils/misc.py:99-195), N^2 boxes per square (right
+    diagonals), rank r owning square r."""
+    from . import mesh as meshmod
+    s = N + 1
+    ny_tot = N * size
+    k0 = max(rank * N - 1, 0)
+    k1 = (rank + 1) * N
+    nyb = k1 - k0
+    nyv = nyb + 1
+    ix = np.tile(np.arange(s), nyv)
+    iy = np.repeat(np.arange(k0, k1 + 1), s)
+    coords = np.column_stack([ix / float(N), iy / float(N)])
+    idx = np.arange(nyb * N)
+    j, i = np.divmod(idx, N)
+    v0 = j * s + i
+    quad = np.column_stack([v0, v0 + 1, v0 + s, v0 + s + 1])
+    tri = np.empty((nyb * N, 2, 3), dtype=np.int32)
+    tri[:, 0, :] = quad[:, [0, 1, 3]]
+    tri[:, 1, :] = quad[:, [0, 2, 3]]
+    cells = tri.reshape(-1, 3)
+    sq_of_cell = np.repeat(np.minimum((j + k0) // N, size - 1), 2)
+    yrel = iy[cells] - (sq_of_cell * N)[:, None]
+    ok_x = ((4 * ix >= N) & (4 * ix <= 3 * N))[cells].all(axis=1)
+    ok_y = ((4 * yrel >= N) & (4 * yrel <= 3 * N)).all(axis=1)
+    tags = np.where(ok_x & ok_y, 1, 2).astype(np.int32)
+    gamma, gtags, _ = meshmod.gamma_integration_entities(cells, tags, (1,), (2,), None)
+    owner = np.minimum(iy // N, size - 1).astype(np.int32)
+    gid = iy.astype(np.int64) * s + ix
+    lm = extract_local(coords * scale, cells, tags, gamma, gtags, owner, rank, global_ids=gid,
+                       n_vertices_global=(ny_tot + 1) * s, n_cells_global=2 * N * ny_tot)
+    lm.description = f"{size} stacked unit squares, N={N} (rank {rank} slab)"
+    return lm
+
+
 class HaloPlan:
     """Send/receive DoF index lists per neighbouring rank (built once after the DoF layout is known)."""
 

@@ -196,18 +196,13 @@ class SolverKNPEMI:
         be = self.backend
         nrm = be.nullspace_test()
         a_scale = max(1e-300, float(self._matrix_scale()))
-        assert nrm <= 1e-8 * a_scale, f"constant potential is not in the null space of A (||A ns|| = {nrm:.3e})"
+        assert nrm <= 1e-10 * a_scale, f"constant potential is not in the null space of A (||A ns|| = {nrm:.3e})"
         be.set_nullspace(True)
         be.project_nullspace(be.b)
         self.print("Null space set.")
 
     def _matrix_scale(self):
-        # ||A||_inf-ish scale from a probe SpMV with the all-ones vector (cheap, setup only)
-        be = self.backend
-        ones = torch.ones(be.n_dof_local, dtype=torch.float64, device=be.device)
-        y = torch.empty(be.n_dof_local, dtype=torch.float64, device=be.device)
-        be.spmv(ones, y)
-        return self.comm.allreduce_max(float(y[:be.n_dof_owned].abs().max().item()) if be.n_dof_owned else 0.0) + 1e-300
+        return self.comm.allreduce_max(self.backend.matrix_max_abs()) + 1e-300
 
     def _sync(self):
         torch.cuda.synchronize()

@@ -904,13 +904,13 @@ struct ProfScope {
     hipEvent_t a = nullptr, b = nullptr;
     int cls;
     ProfScope(knp_ctx* ctx, int cls_) : c(ctx), cls(cls_) {
-        if (c->prof_on) {
+        if ((c->prof_on >> cls) & 1) {
             if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
             (void)hipEventRecord(a, c->stream);
         }
     }
     ~ProfScope() {
-        if (c->prof_on && a && b) {
+        if (a && b) {
             (void)hipEventRecord(b, c->stream);
             c->prof_recs.push_back({a, b, cls});
         }
@@ -1802,7 +1802,7 @@ int knp_l2_norms(knp_ctx* ctx, const double* phi_i, const double* phi_e, double*
 int knp_profile_enable(knp_ctx* ctx, int32_t on) {
     CHECK_CTX(ctx);
     KCHK(prof_collect(ctx));
-    ctx->prof_on = on ? 1 : 0;
+    ctx->prof_on = on;   // bit k enables class k
     return KNP_OK;
 }
 int knp_profile_get(knp_ctx* ctx, int32_t cls, double* ms, int64_t* launches) {

@@ -551,8 +551,10 @@ class OracleKNPEMI:
                 Inkcc1 = 0.0 * Ikcc1
                 cur = [-Inkcc1, -Inkcc1 + Ikcc1, 2.0 * Inkcc1 - Ikcc1]
             elif mdl.kind == "kir_nak":                                         # :125-222
-                K_i_g_init = 100.0
-                E_K_init = psi * math.log(p.K_e_init / K_i_g_init)
+                # E_K_init is frozen in the model constructor (:117), which the reference's drivers call
+                # BEFORE set_initial_conditions (main.py:32-47): it therefore sees the class defaults
+                # K_e_init = 3, K_i_g_init = 100 (KNPEMIx_problem.py:945,960), not the YAML values.
+                E_K_init = psi * math.log(3.0 / 100.0)
                 pump = (1.0 / (1.0 + (10.0 / ki[0]) ** 1.5)) * (1.0 / (1.0 + 1.5 / ke[1])) * (1.1 * 1.12e-6)
                 Fc = p.F
                 dphi = phim - E[1]

@@ -1,0 +1,208 @@
+"""Host-side logic of the native path (no GPU): YAML schema, tags, mesh generators and markers, the
+membrane-expression compiler, the AMG hierarchy builder."""
+import os
+
+import numpy as np
+import pytest
+import yaml
+
+import knpemi_oracle as K
+from cgx_hip import amg, fem
+from cgx_hip import mesh as meshmod
+from cgx_hip.parallel import extract_local, partition_mesh, stacked_cubes_local_mesh, stacked_squares_local_mesh, vertex_partition
+from cgx_hip.problem import range_constructor
+from parity_utils import CI_BASE, ci_config, make_oracle, make_problem
+
+
+def test_yaml_schema_roundtrip(tmp_path):
+    """A config written with the reference's keys (configs/tests/*.yaml) parses into the same attributes."""
+    cfg = ci_config(N=8, steps=3)
+    cfg.pop("quiet")
+    f = tmp_path / "cfg.yaml"
+    f.write_text(yaml.safe_dump(cfg))
+    from CGx.KNPEMI.KNPEMIx_problem import ProblemKNPEMI
+    cfgq = str(f)
+    p = ProblemKNPEMI(cfgq)
+    assert p.time_steps == 3 and p.dt.value == 2.5e-5
+    assert p.intra_tags == (1,) and p.extra_tag == (2,) and p.gamma_tags == (4,) and p.stimulus_tags == (4,)
+    assert abs(p.psi.value - 8.314 * 300 / 96485) < 1e-15 and p.C_M.value == 0.02
+    assert p.g_syn_bar.value == 1e-9 and p.scale_stimulus is True and p.g_Na_leak.value == 0.3
+    assert p.N_ions == 3 and [ion["name"] for ion in p.ion_list] == ["Na", "K", "Cl"]
+    assert [ion["z"].value for ion in p.ion_list] == [1.0, 1.0, -1.0]
+    assert p.solver_config["ksp_settings"]["ksp_rtol"] == 1e-9
+    assert p.mesh.geometry.x.max() == pytest.approx(1e-6)
+
+
+def test_range_tag_and_required_keys(tmp_path):
+    yaml.add_constructor("!range", range_constructor, Loader=yaml.FullLoader)
+    assert yaml.load("a: !range [2, 6]", Loader=yaml.FullLoader)["a"] == [2, 3, 4, 5]
+    from CGx.KNPEMI.KNPEMIx_problem import ProblemKNPEMI
+    for missing in ("solver", "dt", "ics_tags", "cell_tag_file"):
+        cfg = ci_config(N=8)
+        cfg.pop(missing)
+        with pytest.raises(RuntimeError):
+            ProblemKNPEMI(cfg)
+    cfg = ci_config(N=8)
+    cfg["cell_tag_file"] = "tissue.xdmf"
+    with pytest.raises(RuntimeError):
+        ProblemKNPEMI(cfg)
+
+
+def test_ionic_model_tag_mismatch_raises():
+    from CGx.KNPEMI.KNPEMIx_ionic_model import PassiveModel
+    from CGx.KNPEMI.KNPEMIx_problem import ProblemKNPEMI
+    p = ProblemKNPEMI(ci_config(N=8))
+    p.set_initial_conditions()
+    with pytest.raises(RuntimeError):
+        p.init_ionic_models([PassiveModel(p, tags=(7,))])
+
+
+@pytest.mark.parametrize("kind,N", [("square", 8), ("square", 12), ("cube", 4)])
+def test_mesh_generators_and_gamma_match_oracle(kind, N):
+    gen = meshmod.create_unit_square if kind == "square" else meshmod.create_unit_cube
+    ogen = K.unit_square_mesh if kind == "square" else K.unit_cube_mesh
+    c, t = gen(N)
+    oc, ot = ogen(N)
+    assert np.allclose(c, oc) and np.array_equal(t, ot)
+    tags = meshmod.mark_subdomains_box(c, t)
+    assert np.array_equal(tags, K.mark_subdomains(oc, ot))
+    g, gt, _ = meshmod.gamma_integration_entities(t, tags, (1,), (2,))
+    og = K.interface_facets(ot, np.where(tags == 1, 0, 1))
+    assert np.array_equal(g, og) and np.all(gt == 4)
+    # '+' side is intracellular for every facet
+    assert np.all(tags[g[:, 0]] == 1) and np.all(tags[g[:, 2]] == 2)
+
+
+def test_ci_mesh_sizes():
+    c, t = meshmod.create_unit_square(32)
+    tags = meshmod.mark_subdomains_box(c, t)
+    g, _, _ = meshmod.gamma_integration_entities(t, tags, (1,), (2,))
+    assert c.shape[0] == 1089 and t.shape[0] == 2048 and (tags == 1).sum() == 512 and g.shape[0] == 64
+
+
+def test_facet_quadrature_matches_oracle():
+    for dim in (2, 3):
+        p, w = meshmod.facet_quadrature(dim, 10)
+        op, ow = K.facet_quadrature(dim)
+        assert np.allclose(p, op, atol=1e-15) and np.allclose(w, ow, atol=1e-15)
+
+
+def test_membrane_program_matches_oracle_currents():
+    """Compiler + bytecode semantics: interpret the compiled program of the CI mechanism set on the host
+    and compare with the oracle's direct formulas at every membrane quadrature point."""
+    p = make_problem(ci_config(N=16, steps=2))
+    o = make_oracle(16)
+    rng = np.random.default_rng(3)
+    for side in range(2):
+        for j in range(3):
+            o.k[side][j] = o.k[side][j] * (1 + 0.1 * rng.random(o.n_v))
+    o.phi_m = o.phi_m * (1 + 0.1 * rng.random(o.n_v))
+    o.n, o.m, o.h = [a * (1 + 0.1 * rng.random(o.n_v)) for a in (o.n, o.m, o.h)]
+    o.t = 3 * o.p.dt
+    o.update_t_mod()
+    p.t.value = o.t
+    for m in p.ionic_models:
+        if hasattr(m, "update_t_mod"):
+            m.update_t_mod()
+    Iq = o.channel_currents_q()
+    ki = [o._at_q(o.k[0][j]) for j in range(3)]
+    ke = [o._at_q(o.k[1][j]) for j in range(3)]
+    aux = {"n": o._at_q(o.n), "m": o._at_q(o.m), "h": o._at_q(o.h)}
+    spec = p.programs[0]
+    assert spec.code.shape[1] == 4 and spec.code[:, 1].max() < 48
+    out = fem.interpret_program(spec, ki, ke, o._at_q(o.phi_m), [aux[f.name] for f in p.aux_functions], [None] * 3)
+    for j in range(3):
+        assert np.max(np.abs(out[j] - Iq[j])) <= 1e-13 * np.max(np.abs(Iq[j]))
+
+
+def test_expression_layer_semantics():
+    m = type("M", (), {})()
+    c = fem.Constant(m, 2.0)
+    e = fem.conditional(fem.And(fem.gt(c, 1.0), fem.lt(c, 3.0)), c ** 3 + fem.sqrt(c) - fem.ln(c) / fem.exp(c), -1.0)
+    assert bool(e) is True                               # UFL truthiness (f_NKCC1 quirk)
+    v = fem.evaluate_numpy(e, {"x": [], "fields": {}})
+    assert v == pytest.approx(8 + np.sqrt(2) - np.log(2) / np.exp(2))
+    spec = fem.compile_program([e, 2 * c, c ** (3 / 2)], {})
+    out = fem.interpret_program(spec, [0] * 3, [0] * 3, 0.0, [], [0] * 3)
+    assert out[0] == pytest.approx(v) and out[1] == 4.0 and out[2] == pytest.approx(2 ** 1.5)
+    c.value = 5.0                                        # constants are re-read at every upload
+    out = fem.interpret_program(spec, [0] * 3, [0] * 3, 0.0, [], [0] * 3)
+    assert out[0] == -1.0 and out[1] == 10.0
+
+
+def test_passive_and_glial_models_compile():
+    from CGx.KNPEMI.KNPEMIx_ionic_model import GlialCotransporters, KirNaKPumpModel
+    p = make_problem(ci_config(N=8), models=lambda pr: [KirNaKPumpModel(pr), GlialCotransporters(pr)])
+    o = K.make_square(8, models=[K.Model("kir_nak", (4,)), K.Model("glial_ct", (4,))])
+    Iq = o.channel_currents_q()
+    ki = [o._at_q(o.k[0][j]) for j in range(3)]
+    ke = [o._at_q(o.k[1][j]) for j in range(3)]
+    out = fem.interpret_program(p.programs[0], ki, ke, o._at_q(o.phi_m), [], [None] * 3)
+    for j in range(3):
+        assert np.max(np.abs(out[j] - Iq[j])) <= 1e-12 * np.max(np.abs(Iq[j]))
+
+
+def test_amg_hierarchy_is_a_contraction():
+    """Setup-side check: the hierarchy built for P, applied with the reference V-cycle, reduces the error of
+    every elliptic block of P; GMRES on the CI problem converges in the reference's ~3 iterations."""
+    o = make_oracle(32)
+    P = o.assemble_P()
+    h = amg.build_hierarchy(P)
+    d = h.describe()
+    assert len(d["rows"]) >= 2 and d["operator_complexity"] < 1.6
+    M = K.pc_amg_vcycle(h.levels, h.coarse_inv, 1, 1, 2)
+    rng = np.random.default_rng(0)
+    xt = rng.standard_normal(P.shape[0])
+    b = P @ xt
+    x = np.zeros_like(b)
+    for _ in range(12):
+        x = x + M(b - P @ x)
+    # concentration blocks (SPD): fast contraction
+    for f in range(3):
+        assert np.linalg.norm((x - xt)[f::4]) <= 1e-3 * np.linalg.norm(xt[f::4])
+    o2 = make_oracle(32)
+    _, its = o2.run(3, solver="gmres", pc=lambda PP: K.pc_amg_vcycle(*(lambda hh: (hh.levels, hh.coarse_inv))(amg.build_hierarchy(PP)), 1, 1, 2), rtol=1e-9)
+    assert max(its) <= 6
+
+
+def test_aggregation_covers_all_nodes():
+    o = make_oracle(16)
+    P = o.assemble_P()
+    S = amg.strength_graph(P, 0.08)
+    agg, nagg = amg.aggregate(S)
+    assert agg.min() == 0 and agg.max() == nagg - 1 and len(np.unique(agg)) == nagg
+    # aggregates never mix fields or sides
+    for a in range(0, nagg, max(1, nagg // 50)):
+        members = np.nonzero(agg == a)[0]
+        assert len(set(members % 4)) == 1
+        assert len(set(o.lay.node_side[members // 4])) == 1
+
+
+@pytest.mark.parametrize("size", [2, 3])
+def test_partition_covers_mesh_once(size):
+    c, t = meshmod.create_unit_square(12)
+    tags = meshmod.mark_subdomains_box(c, t)
+    g, gt, _ = meshmod.gamma_integration_entities(t, tags, (1,), (2,))
+    seen_v = np.zeros(c.shape[0], int)
+    seen_c = 0
+    for r in range(size):
+        lm = partition_mesh(c, t, tags, g, gt, size, r)
+        seen_v[lm.l2g[:lm.n_vertices_owned]] += 1
+        seen_c += lm.n_cells_owned
+        # every cell touching an owned vertex is local
+        owner = vertex_partition(c, size)
+        assert lm.cells.shape[0] == int((owner[t] == r).any(axis=1).sum())
+        assert np.allclose(lm.coords, c[lm.l2g])
+        assert np.all(lm.ghost_owner != r)
+    assert np.all(seen_v == 1) and seen_c == t.shape[0]
+
+
+def test_stacked_generators_equal_global_mesh_on_one_rank():
+    lm = stacked_squares_local_mesh(8, 1, 0)
+    c, t = meshmod.create_unit_square(8)
+    assert np.allclose(lm.coords, c) and lm.cells.shape == t.shape and lm.n_vertices_owned == c.shape[0]
+    assert sorted(map(tuple, np.sort(lm.cells, axis=1).tolist())) == sorted(map(tuple, np.sort(t, axis=1).tolist()))
+    lm3 = stacked_cubes_local_mesh(4, 1, 0)
+    c3, t3 = meshmod.create_unit_cube(4)
+    assert np.allclose(lm3.coords, c3) and lm3.cells.shape == t3.shape
+    assert (lm3.cell_tags == 1).sum() == (meshmod.mark_subdomains_box(c3, t3) == 1).sum()

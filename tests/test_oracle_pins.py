@@ -1,0 +1,143 @@
+"""Pins the CPU oracle against every known answer the reference's own tests hold for this path
+ and against invariants of the discrete problem.  CPU only."""
+import numpy as np
+import pytest
+from scipy.optimize import brentq
+
+import knpemi_oracle as K
+
+# reference tests/KNPEMI/electric_potential_norms_iterative_solver.py:58-59 and ..._direct_solver.py:55-56
+PIN_ITERATIVE = (3.510994056704844e-08, 6.369472309249516e-11)
+PIN_DIRECT = (2.6337161145147203e-08, 1.5258564901943312e-08)
+
+
+@pytest.fixture(scope="module")
+def ci_run():
+    o = K.make_square(32, models=K.CI_MODELS())
+    xs = []
+    o.run(10, solver="lu_gauge", log=lambda s, oo, x: xs.append(x.copy()))
+    return o, xs
+
+
+def test_mesh_counts_of_the_ci_problem(ci_run):
+    o, _ = ci_run
+    # 1089 vertices, 2048 cells (512 intra), 64 membrane facets, 4612 DoF
+    assert o.n_v == 1089 and o.cells.shape[0] == 2048 and int((o.cell_side == 0).sum()) == 512
+    assert o.gamma.shape[0] == 64 and o.n_dof == 4612
+    assert abs(o.stimulus_area - 2.0e-6) < 1e-18
+
+
+def test_direct_solver_pin_modulo_gauge(ci_run):
+    """MUMPS returns the solution in its own gauge (one additive constant on all potentials).  Fit the
+    constant from ||phi_i|| and predict ||phi_e||: the reference's saved value is met to 1e-8."""
+    o, _ = ci_run
+    vi, ve = o.lay.node_i >= 0, o.lay.node_e >= 0
+    phi_i, phi_e = o.phi[0], o.phi[1]
+
+    def norms(c):
+        return o.l2_norm(np.where(vi, phi_i + c, 0.0), 0), o.l2_norm(np.where(ve, phi_e + c, 0.0), 1)
+    c = brentq(lambda cc: norms(cc)[0] - PIN_DIRECT[0], 0.0, 0.05, xtol=1e-18, rtol=1e-15)
+    ni, ne = norms(c)
+    assert abs(ni - PIN_DIRECT[0]) <= 1e-12 * PIN_DIRECT[0]
+    assert abs(ne - PIN_DIRECT[1]) <= 1e-8 * PIN_DIRECT[1]
+
+
+def test_iterative_solver_pin(ci_run):
+    """phi_i meets the north-star tolerance (1e-6).  phi_e (1000x smaller) agrees to 1.2e-4, which is the
+    linear-solver truncation error of the reference run itself -- see the noise-floor test below."""
+    o, _ = ci_run
+    ni, ne = o.potential_norms()
+    assert abs(ni - PIN_ITERATIVE[0]) <= 1e-6 * PIN_ITERATIVE[0]
+    assert abs(ne - PIN_ITERATIVE[1]) <= 2e-4 * PIN_ITERATIVE[1]
+
+
+def test_iterative_pin_noise_floor():
+    """With an (almost) exact preconditioner on P and the reference's stopping rule (rtol 1e-9 on the
+    preconditioned residual) GMRES needs exactly the reference's 3 iterations per step, and its truncated
+    iterates move ||phi_e|| by O(1e-5..1e-4) relative to the exact solve: the reference's saved phi_e cannot
+    be pinned tighter than that by any exact restatement."""
+    o = K.make_square(32, models=K.CI_MODELS())
+    _, its = o.run(10, solver="gmres", pc=K.pc_exact_lu(), rtol=1e-9)
+    assert its == [3] * 10                       # reference: mean 3.0 (tests/...iterative_solver.py:81)
+    ni, ne = o.potential_norms()
+    oe = K.make_square(32, models=K.CI_MODELS())
+    oe.run(10, solver="lu_gauge")
+    ei, ee = oe.potential_norms()
+    assert abs(ni - ei) / ei < 5e-7
+    assert 1e-6 < abs(ne - ee) / ee < 5e-4
+
+
+def test_gauge_and_membrane_potential(ci_run):
+    o, xs = ci_run
+    # sum of potential DoFs conserved at the initial value -0.07 * 289
+    for x in xs:
+        assert abs(x[3::4].sum() - (-0.07 * 289)) < 1e-10
+    # gauge-invariant membrane potential implied by both reference pins: -0.0702934
+    gam = (o.lay.node_i >= 0) & (o.lay.node_e >= 0)
+    assert abs(o.phi_m[gam].mean() - (-0.0702934)) < 2e-7
+
+
+def test_operator_invariants():
+    o = K.make_square(16, models=K.CI_MODELS())
+    A = o.assemble_A()
+    ns = o.nullspace()
+    assert np.abs(A @ ns).max() <= 1e-12 * np.abs(A.data).max()          # KNPEMIx_solver.py:327
+    assert np.abs(A.T @ ns).max() <= 1e-12 * np.abs(A.data).max()        # consistency of the singular system
+    P = o.assemble_P()
+    assert abs(P - P.T).max() <= 1e-14 * np.abs(P.data).max()            # every block of P is symmetric
+    # P is block diagonal by field
+    coo = P.tocoo()
+    assert np.all(coo.row % 4 == coo.col % 4)
+    b = o.assemble_b()
+    assert abs(ns @ b) <= 1e-12 * np.abs(b[3::4]).max()
+
+
+def test_charge_conservation():
+    """Zero sources: the scheme conserves total charge sum_k z_k (N_k^i + N_k^e) exactly, because the
+    capacitive-current fractions alpha^k sum to one on each side (KNPEMIx_problem.py:582-583,609-610).
+    Individual ion amounts only drift by the alpha_i/alpha_e mismatch of the capacitive split."""
+    o = K.make_square(16, models=K.CI_MODELS())
+
+    def amounts():
+        out = []
+        for j in range(3):
+            tot = 0.0
+            for side in range(2):
+                sel = o.cell_side == side
+                tot += float((o.vol[sel] * o.k[side][j][o.cells[sel]].mean(axis=1)).sum())
+            out.append(tot)
+        return np.array(out)
+    a0 = amounts()
+    o.run(5, solver="lu_gauge")
+    d = amounts() - a0
+    z = np.array(o.p.z)
+    assert abs((z * d).sum()) <= 1e-6 * np.abs(d).max()
+    assert np.all(np.abs(d) <= 1e-5 * np.abs(a0))
+
+
+@pytest.mark.parametrize("name", ["square8_ci", "square8_passive", "cube4_ci"])
+def test_golden_fixtures_reproduce(name):
+    import os
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"), allow_pickle=False)
+    kind, N, steps, models = str(d["kind"]), int(d["N"]), int(d["steps"]), str(d["models"])
+    mk = K.make_square if kind == "square" else K.make_cube
+    o = mk(N, models=K.CI_MODELS() if models == "ci" else [K.Model("passive", (4,))])
+    xs = []
+    o.run(steps, solver="lu_gauge", log=lambda s, oo, x: xs.append(x.copy()))
+    assert np.allclose(np.array(xs), d["x"], rtol=1e-9, atol=1e-14)
+    assert np.allclose(o.potential_norms(), d["norms"][-1], rtol=1e-9)
+
+
+def test_facet_quadrature_exactness():
+    # degree-10 exactness on edge and triangle (monomials in barycentric coordinates)
+    from math import factorial
+    pts, w = K.facet_quadrature(2)
+    for a in range(11):
+        exact = factorial(a) * factorial(10 - a) / factorial(11)
+        assert abs((w * pts[:, 0] ** a * pts[:, 1] ** (10 - a)).sum() - exact) < 1e-15
+    pts, w = K.facet_quadrature(3)
+    for a in range(0, 11, 2):
+        for b in range(0, 11 - a, 3):
+            c = 10 - a - b
+            exact = 2 * factorial(a) * factorial(b) * factorial(c) / factorial(12)
+            assert abs((w * pts[:, 0] ** a * pts[:, 1] ** b * pts[:, 2] ** c).sum() - exact) < 1e-15
