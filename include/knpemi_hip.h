@@ -18,6 +18,7 @@
  *                                    form KNPEMIx_problem.py:657-744)
  *   knp_set_nullspace / knp_project_nullspace
  *        MatNullSpace create/test/remove                              (KNPEMIx_solver.py:297-335)
+ *   knp_set_deflation                (multi-GPU only) restores what BoomerAMG's global coarse levels give the reference
  *   knp_pc_setup / knp_amg_*         PC setup: ksp.setUp() with pc_type hypre (KNPEMIx_solver.py:211-214,
  *                                    269-273, 386-389) -> vertex-block Jacobi / aggregation AMG
  *   knp_gmres_solve                  ksp.solve(b, x): GMRES(30), left PC, CGS, preconditioned norm
@@ -176,6 +177,11 @@ int knp_project_nullspace(knp_ctx* ctx, double* v);
 int knp_nullspace_test(knp_ctx* ctx, double* out_norm /* host: ||A ns||_2 */);
 int knp_pc_setup(knp_ctx* ctx, int32_t kind);
 int knp_pc_apply(knp_ctx* ctx, const double* r, double* z);
+/* Additive coarse correction for near-null modes the per-GPU preconditioner blocks cannot see (constants of a
+ * potential block on a connected component that the partition cuts): z += Z Einv Z^T r with Z the indicator
+ * vectors of the potential DoFs of each mode. node_mode: host [n_nodes_owned], -1 = not deflated.
+ * Einv: host [n_modes^2] (pseudo-)inverse of Z^T A Z, identical on every rank. n_modes = 0 disables. */
+int knp_set_deflation(knp_ctx* ctx, int32_t n_modes, const int32_t* node_mode, const double* einv);
 /* AMG hierarchy supplied level by level (level 0 = finest = P itself). All arrays HOST; copied. */
 int knp_amg_reset(knp_ctx* ctx, int32_t n_levels, int32_t pre_sweeps, int32_t post_sweeps, int32_t cheby_degree);
 int knp_amg_set_level(knp_ctx* ctx, int32_t level, int32_t n_rows, int32_t n_cols_halo,

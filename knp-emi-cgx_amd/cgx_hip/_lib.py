@@ -78,6 +78,7 @@ SIGNATURES = {
     "knp_nullspace_test": (C.c_int, [vp, f64p]),
     "knp_pc_setup": (C.c_int, [vp, C.c_int32]),
     "knp_pc_apply": (C.c_int, [vp, vp, vp]),
+    "knp_set_deflation": (C.c_int, [vp, C.c_int32, i32p, f64p]),
     "knp_amg_reset": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "knp_amg_set_level": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, i32p, i32p, f64p, f64p, C.c_double,
                                     C.c_int32, i32p, i32p, f64p, i32p, i32p, f64p]),

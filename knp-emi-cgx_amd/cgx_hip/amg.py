@@ -125,7 +125,7 @@ class Hierarchy:
                 "grid_complexity": float(sum(rows)) / max(rows[0], 1)}
 
 
-def build_hierarchy(P: sp.csr_matrix, theta: float = 0.08, max_levels: int = 12, coarse_size: int = 1200,
+def build_hierarchy(P: sp.csr_matrix, theta: float = 0.08, max_levels: int = 12, coarse_size: int = 2500,
                     smooth_prolongator: bool = True) -> Hierarchy:
     A = sp.csr_matrix(P, dtype=np.float64)
     A.sort_indices()

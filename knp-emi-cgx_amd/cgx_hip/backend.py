@@ -101,6 +101,36 @@ class Backend:
             self.check(self.lib.knp_set_comm(self.ctx, self._halo_cb, self._ar_cb, None))
         if getattr(problem, "programs", None):
             self.upload_programs()
+        self.setup_deflation()
+
+    def setup_deflation(self):
+        """Multi-GPU only: coarse correction for the floating-potential modes cut by the partition
+        (E = Z^T A Z only involves the membrane capacitance terms: KNPEMIx_problem.py:637-638)."""
+        p = self.p
+        lm = p.local_mesh
+        d = getattr(lm, "defl", None)
+        if p.comm.size == 1 or not d:
+            return
+        m = int(d["n_modes"])
+        nvo = lm.n_vertices_owned
+        node_mode = np.full(self.n_nodes_owned, -1, dtype=np.int32)
+        vi = np.nonzero(self.node_i[:nvo] >= 0)[0]
+        node_mode[self.node_i[vi]] = d["vertex_mode_i"][vi]
+        ve = np.nonzero(self.node_e[:nvo] >= 0)[0]
+        node_mode[self.node_e[ve]] = d["ecs_mode"]
+        total = d["total_area"]
+        if total is None:
+            total = p.integrate_over_membrane(1.0, p.gamma_tags)
+        kappa = float(p.C_M.value) / float(p.F.value)
+        E = np.zeros((m, m))
+        e = int(d["ecs_mode"])
+        for k, a in enumerate(d["areas"]):
+            E[k, k] = kappa * a
+            E[k, e] = E[e, k] = -kappa * a
+        E[e, e] = kappa * total
+        Einv = np.ascontiguousarray(np.linalg.pinv(E, rcond=1e-12))
+        self.deflation = {"E": E, "node_mode": node_mode}
+        self.check(self.lib.knp_set_deflation(self.ctx, m, _i32(node_mode), _f64(Einv)))
 
     # ------------------------------------------------------------------ helpers
     def check(self, rc):

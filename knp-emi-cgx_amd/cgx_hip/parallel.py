@@ -71,6 +71,10 @@ class LocalMesh:
     n_vertices_global: int = 0
     n_cells_global: int = 0
     description: str = ""
+    # deflation of near-null potential modes cut by the partition (None on one rank):
+    # {"vertex_mode_i": int32 per local vertex (-1 = intra node not deflated), "ecs_mode": int, "n_modes": int,
+    #  "areas": membrane measure of each deflated intra component (global), "total_area": float | None}
+    defl: dict | None = None
 
 
 def vertex_partition(coords, size):
@@ -136,9 +140,50 @@ def extract_local(coords, cells, cell_tags, gamma, gamma_tags, vertex_owner, ran
                      n_cells_global=int(n_cells_global if n_cells_global is not None else cells.shape[0]))
 
 
-def partition_mesh(coords, cells, cell_tags, gamma, gamma_tags, size, rank) -> LocalMesh:
+def partition_mesh(coords, cells, cell_tags, gamma, gamma_tags, size, rank, intra_tags=None, max_modes=32) -> LocalMesh:
     owner = vertex_partition(coords, size)
-    return extract_local(coords, cells, cell_tags, gamma, gamma_tags, owner, rank)
+    lm = extract_local(coords, cells, cell_tags, gamma, gamma_tags, owner, rank)
+    if size > 1 and intra_tags is not None:
+        lm.defl = cut_component_modes(coords, cells, np.isin(cell_tags, intra_tags), gamma, owner, lm.l2g, max_modes)
+    return lm
+
+
+def cut_component_modes(coords, cells, is_intra_cell, gamma, vertex_owner, l2g, max_modes=32):
+    """Deflation modes for a partitioned mesh: the extracellular space plus every connected intracellular
+    component whose vertices are spread over more than one rank (a per-rank preconditioner block cannot see
+    the floating-constant mode of such a component)."""
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import connected_components
+    nv = coords.shape[0]
+    ic = cells[is_intra_cell]
+    rows = np.repeat(ic[:, 0], ic.shape[1] - 1)
+    cols = ic[:, 1:].ravel()
+    g = sp.coo_matrix((np.ones(len(rows)), (rows, cols)), shape=(nv, nv))
+    _, lab = connected_components(g, directed=False)
+    intra_v = np.zeros(nv, dtype=bool)
+    intra_v[ic.ravel()] = True
+    lab = np.where(intra_v, lab, -1)
+    comps = np.unique(lab[intra_v])
+    # cut components: more than one owner among their vertices
+    cut = []
+    for c in comps:
+        ow = vertex_owner[lab == c]
+        if ow.min() != ow.max():
+            cut.append(c)
+    # membrane measure per component
+    d = coords.shape[1]
+    loc = np.array([[a for a in range(d + 1) if a != lf] for lf in range(d + 1)])
+    fv = cells[gamma[:, 0][:, None], loc[gamma[:, 1]]]
+    X = coords[fv]
+    meas = np.linalg.norm(X[:, 1] - X[:, 0], axis=1) if d == 2 else \
+        0.5 * np.linalg.norm(np.cross(X[:, 1] - X[:, 0], X[:, 2] - X[:, 0]), axis=1)
+    fcomp = lab[fv[:, 0]]
+    areas_all = {int(c): float(meas[fcomp == c].sum()) for c in comps}
+    cut = sorted(cut, key=lambda c: -areas_all[int(c)])[:max(max_modes - 1, 0)]
+    mode_of = {int(c): k for k, c in enumerate(cut)}
+    vmode_global = np.array([mode_of.get(int(c), -1) for c in lab], dtype=np.int32)
+    return {"vertex_mode_i": vmode_global[l2g], "ecs_mode": len(cut), "n_modes": len(cut) + 1,
+            "areas": np.array([areas_all[int(c)] for c in cut]), "total_area": float(meas.sum())}
 
 
 def stacked_cubes_local_mesh(N, size, rank, scale=1.0) -> LocalMesh:
@@ -176,6 +221,9 @@ def stacked_cubes_local_mesh(N, size, rank, scale=1.0) -> LocalMesh:
     lm = extract_local(coords * scale, cells, tags, gamma, gtags, owner, rank, global_ids=gid,
                        n_vertices_global=(nz_tot + 1) * s * s, n_cells_global=6 * N * N * nz_tot)
     lm.description = f"{size} stacked unit cubes, N={N} (rank {rank} slab)"
+    if size > 1:   # inclusions never touch a slab interface: only the extracellular constant is cut
+        lm.defl = {"vertex_mode_i": np.full(lm.coords.shape[0], -1, dtype=np.int32), "ecs_mode": 0, "n_modes": 1,
+                   "areas": np.zeros(0), "total_area": None}
     return lm
 
 
@@ -212,6 +260,9 @@ def stacked_squares_local_mesh(N, size, rank, scale=1.0) -> LocalMesh:
     lm = extract_local(coords * scale, cells, tags, gamma, gtags, owner, rank, global_ids=gid,
                        n_vertices_global=(ny_tot + 1) * s, n_cells_global=2 * N * ny_tot)
     lm.description = f"{size} stacked unit squares, N={N} (rank {rank} slab)"
+    if size > 1:
+        lm.defl = {"vertex_mode_i": np.full(lm.coords.shape[0], -1, dtype=np.int32), "ecs_mode": 0, "n_modes": 1,
+                   "areas": np.zeros(0), "total_area": None}
     return lm
 
 

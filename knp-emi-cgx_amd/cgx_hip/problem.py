@@ -300,7 +300,7 @@ class MixedDimensionalProblem(ABC):
             gamma, gtags, gverts = meshmod.gamma_integration_entities(cells, cell_tags, self.intra_tags, self.extra_tag, facet_tags)
             keep = np.isin(gtags, self.gamma_tags)
             gamma, gtags = gamma[keep], gtags[keep]
-            lm = partition_mesh(coords, cells, cell_tags, gamma, gtags, self.comm.size, self.comm.rank)
+            lm = partition_mesh(coords, cells, cell_tags, gamma, gtags, self.comm.size, self.comm.rank, intra_tags=self.intra_tags)
             lm.description = desc
         self.local_mesh = lm
         self.mesh = meshmod.Mesh(lm.coords, lm.cells)

@@ -73,6 +73,7 @@ class SolverKNPEMI:
     amg_cheby_degree = 2
     amg_pre = 1
     amg_post = 1
+    amg_coarse_size = 2500
 
     def __init__(self, problem: ProblemKNPEMI, solver_config: dict):
         self.problem = problem
@@ -104,7 +105,7 @@ class SolverKNPEMI:
             if "ksp_max_it" in ks: self.ksp_max_it = int(ks["ksp_max_it"])
             if "gmres_restart" in ks: self.gmres_restart = int(ks["gmres_restart"])
             if "strict" in ks: self.strict = bool(ks["strict"])
-            for k in ("amg_theta", "amg_cheby_degree", "amg_pre", "amg_post"):
+            for k in ("amg_theta", "amg_cheby_degree", "amg_pre", "amg_post", "amg_coarse_size"):
                 if k in ks: setattr(self, k, type(getattr(self, k))(ks[k]))
         if self.ksp_type != "gmres":
             raise NotImplementedError(f"ksp_type '{self.ksp_type}': only 'gmres' is implemented natively.")
@@ -138,7 +139,7 @@ class SolverKNPEMI:
             tic = time.perf_counter()
             P = be.precond_csr()
             P = P[:, :be.n_dof_owned].tocsr()          # per-rank block (block-Jacobi across GPUs)
-            self.hierarchy = amg.build_hierarchy(P, theta=self.amg_theta)
+            self.hierarchy = amg.build_hierarchy(P, theta=self.amg_theta, coarse_size=self.amg_coarse_size)
             amg.upload(be.lib, be.ctx, be.check, self.hierarchy, self.amg_pre, self.amg_post, self.amg_cheby_degree)
             self.amg_setup_time = time.perf_counter() - tic
             self.print(f"AMG hierarchy: {self.hierarchy.describe()} (host setup {self.amg_setup_time:0.3f} s)")

@@ -66,7 +66,7 @@ struct KnpAmgLevel {
     double* P_v = nullptr;
     int32_t *R_rp = nullptr, *R_ci = nullptr;
     double* R_v = nullptr;
-    double *x = nullptr, *b = nullptr, *r = nullptr, *d = nullptr;  // work vectors
+    double *x = nullptr, *b = nullptr, *r = nullptr, *d = nullptr, *r2 = nullptr;  // work vectors (x / r2 ping-pong)
     int A_lanes = 8, P_lanes = 4, R_lanes = 8;
 };
 
@@ -138,6 +138,13 @@ struct knp_ctx {
     double* d_partial = nullptr; // reduction scratch
     double* d_red = nullptr;     // [64] reduced values
     double* h_red = nullptr;     // pinned host mirror
+    double* h_red_dev = nullptr; // device-visible address of h_red (zero-copy read-back)
+    double* mirror() const { return allreduce ? nullptr : h_red_dev; }
+    int64_t phi_count_cached = -1;
+    // deflation
+    int defl_m = 0;
+    int32_t* d_defl_mode = nullptr;
+    double* d_defl_einv = nullptr;
     double* d_y = nullptr;       // [restart+1]
     int n_red_blocks = 0;
     // comm

@@ -43,7 +43,9 @@
 
 static constexpr int NT = 256;          // threads per block everywhere
 static constexpr int RED_BLOCKS = 1024; // reduction partial blocks (4 per CU on 256 CUs)
-static constexpr int RED_SLOTS = 64;    // reduced-value slots
+static constexpr int RED_SLOTS = 128;   // reduced-value slots: 0..56 Gram-Schmidt, 58..63 misc, 64..95 deflation sums
+static constexpr int DEFL_SLOT0 = 64;
+static constexpr int DEFL_MAX = 32;
 
 struct DevParams {
     double dt, F, C_M, psi;
@@ -212,11 +214,12 @@ __device__ void run_program(const int32_t* __restrict__ code, int n_instr, const
 }
 
 // ------------------------------------------------------------------------------------------
-// K2: membrane facet quadrature.  One thread per facet.
+// K2: membrane facet quadrature.  LF lanes per facet, each lane takes the quadrature points q = lane,
+//     lane+LF, ...; partial sums are combined with a fixed shuffle tree (deterministic).
 //   fmat[(k*NPK + ab)*n_g + g], k = 0..2 intra ions, 3..5 extra ions : M_Gamma[alpha^k C_M/(F z_k)]
 //   fvec[(k*DIM + a)*n_g + g],  k = 0..2 intra, 3..5 extra, 6 potential
 // ------------------------------------------------------------------------------------------
-template <int DIM, bool MAT, bool VEC>
+template <int DIM, bool MAT, bool VEC, int LF>
 __global__ void __launch_bounds__(NT)
 k_gamma_facets(int n_g, int n_q, DevParams P, const int32_t* __restrict__ fv, const double* __restrict__ fmeas,
                const double* __restrict__ qp, const double* __restrict__ qw, FieldPtrs f, int n_aux,
@@ -225,8 +228,10 @@ k_gamma_facets(int n_g, int n_q, DevParams P, const int32_t* __restrict__ fv, co
                const double* const* __restrict__ prog_consts, double* __restrict__ fmat,
                double* __restrict__ fvec) {
     constexpr int NPK = DIM * (DIM + 1) / 2;
-    const int g = blockIdx.x * NT + threadIdx.x;
-    if (g >= n_g) return;
+    const int g_raw = (blockIdx.x * NT + threadIdx.x) / LF;
+    const int qlane = threadIdx.x & (LF - 1);
+    const bool live = g_raw < n_g;
+    const int g = live ? g_raw : n_g - 1;      // idle lanes shadow the last facet so that shuffles stay uniform
     int v[DIM];
 #pragma unroll
     for (int a = 0; a < DIM; ++a) v[a] = fv[(size_t)g * DIM + a];
@@ -256,7 +261,7 @@ k_gamma_facets(int n_g, int n_q, DevParams P, const int32_t* __restrict__ fv, co
             for (int a = 0; a < DIM; ++a) av[k][a] = 0.0;
     }
     const int prog = VEC ? gamma_prog[g] : 0;
-    for (int q = 0; q < n_q; ++q) {
+    for (int q = qlane; q < n_q; q += LF) {
         double lam[DIM];
 #pragma unroll
         for (int a = 0; a < DIM; ++a) lam[a] = qp[q * DIM + a];
@@ -340,13 +345,23 @@ k_gamma_facets(int n_g, int n_q, DevParams P, const int32_t* __restrict__ fv, co
 #pragma unroll
         for (int k = 0; k < 6; ++k)
 #pragma unroll
-            for (int i = 0; i < NPK; ++i) fmat[((size_t)k * NPK + i) * n_g + g] = am[k][i];
+            for (int i = 0; i < NPK; ++i) {
+                double t = am[k][i];
+#pragma unroll
+                for (int o = LF >> 1; o > 0; o >>= 1) t += __shfl_xor(t, o, LF);
+                if (live && qlane == 0) fmat[((size_t)k * NPK + i) * n_g + g] = t;
+            }
     }
     if (VEC) {
 #pragma unroll
         for (int k = 0; k < 7; ++k)
 #pragma unroll
-            for (int a = 0; a < DIM; ++a) fvec[((size_t)k * DIM + a) * n_g + g] = av[k][a];
+            for (int a = 0; a < DIM; ++a) {
+                double t = av[k][a];
+#pragma unroll
+                for (int o = LF >> 1; o > 0; o >>= 1) t += __shfl_xor(t, o, LF);
+                if (live && qlane == 0) fvec[((size_t)k * DIM + a) * n_g + g] = t;
+            }
     }
 }
 
@@ -457,9 +472,9 @@ k_rhs(int n_nodes_owned, int n_g, int dim, double dt, const int32_t* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------
-// K4: CSR SpMV, L lanes per row.  mode 0: y = A x ; mode 1: y = b - A x
+// K4: CSR SpMV, L lanes per row.  mode 0: y = A x ; mode 1: y = b - A x ; mode 2: y += A x
 // ------------------------------------------------------------------------------------------
-template <int L, int MODE>
+template <int L, int MODE, int TAG>   // TAG 1 = the system matrix A (own symbol for profilers), 0 = AMG level operators
 __global__ void __launch_bounds__(NT)
 k_spmv(int n_rows, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci, const double* __restrict__ v,
        const double* __restrict__ x, const double* __restrict__ b, double* __restrict__ y) {
@@ -473,20 +488,24 @@ k_spmv(int n_rows, const int32_t* __restrict__ rp, const int32_t* __restrict__ c
     }
 #pragma unroll
     for (int o = L >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, L);
-    if (lane == 0 && row < n_rows) y[row] = MODE ? b[row] - s : s;
+    if (lane == 0 && row < n_rows) {
+        if (MODE == 0) y[row] = s;
+        else if (MODE == 1) y[row] = b[row] - s;
+        else y[row] += s;
+    }
 }
 
-template <int MODE>
+template <int MODE, int TAG = 0>
 static void launch_spmv(hipStream_t st, int lanes, int n_rows, const int32_t* rp, const int32_t* ci,
                         const double* v, const double* x, const double* b, double* y) {
     if (n_rows <= 0) return;
     switch (lanes) {
-        case 2: hipLaunchKernelGGL((k_spmv<2, MODE>), dim3(nblocks((int64_t)n_rows * 2)), dim3(NT), 0, st, n_rows, rp, ci, v, x, b, y); break;
-        case 4: hipLaunchKernelGGL((k_spmv<4, MODE>), dim3(nblocks((int64_t)n_rows * 4)), dim3(NT), 0, st, n_rows, rp, ci, v, x, b, y); break;
-        case 8: hipLaunchKernelGGL((k_spmv<8, MODE>), dim3(nblocks((int64_t)n_rows * 8)), dim3(NT), 0, st, n_rows, rp, ci, v, x, b, y); break;
-        case 16: hipLaunchKernelGGL((k_spmv<16, MODE>), dim3(nblocks((int64_t)n_rows * 16)), dim3(NT), 0, st, n_rows, rp, ci, v, x, b, y); break;
-        case 32: hipLaunchKernelGGL((k_spmv<32, MODE>), dim3(nblocks((int64_t)n_rows * 32)), dim3(NT), 0, st, n_rows, rp, ci, v, x, b, y); break;
-        default: hipLaunchKernelGGL((k_spmv<64, MODE>), dim3(nblocks((int64_t)n_rows * 64)), dim3(NT), 0, st, n_rows, rp, ci, v, x, b, y); break;
+        case 2: hipLaunchKernelGGL((k_spmv<2, MODE, TAG>), dim3(nblocks((int64_t)n_rows * 2)), dim3(NT), 0, st, n_rows, rp, ci, v, x, b, y); break;
+        case 4: hipLaunchKernelGGL((k_spmv<4, MODE, TAG>), dim3(nblocks((int64_t)n_rows * 4)), dim3(NT), 0, st, n_rows, rp, ci, v, x, b, y); break;
+        case 8: hipLaunchKernelGGL((k_spmv<8, MODE, TAG>), dim3(nblocks((int64_t)n_rows * 8)), dim3(NT), 0, st, n_rows, rp, ci, v, x, b, y); break;
+        case 16: hipLaunchKernelGGL((k_spmv<16, MODE, TAG>), dim3(nblocks((int64_t)n_rows * 16)), dim3(NT), 0, st, n_rows, rp, ci, v, x, b, y); break;
+        case 32: hipLaunchKernelGGL((k_spmv<32, MODE, TAG>), dim3(nblocks((int64_t)n_rows * 32)), dim3(NT), 0, st, n_rows, rp, ci, v, x, b, y); break;
+        default: hipLaunchKernelGGL((k_spmv<64, MODE, TAG>), dim3(nblocks((int64_t)n_rows * 64)), dim3(NT), 0, st, n_rows, rp, ci, v, x, b, y); break;
     }
 }
 
@@ -526,13 +545,16 @@ k_multi_dot(int n, int64_t ldv, int i0, int m, const double* __restrict__ V, con
 
 // out[slot0 + i] = sum_b partial[i*RED_BLOCKS + b], one block per i
 __global__ void __launch_bounds__(NT) k_reduce_partials(int nb, const double* __restrict__ partial,
-                                                        double* __restrict__ out, int slot0) {
+                                                        double* __restrict__ out, int slot0, double* host_mirror) {
     __shared__ double sm[NT / 64];
     const int i = blockIdx.x;
     double a = 0.0;
     for (int b = threadIdx.x; b < nb; b += NT) a += partial[(size_t)i * RED_BLOCKS + b];
     a = block_sum(a, sm);
-    if (threadIdx.x == 0) out[slot0 + i] = a;
+    if (threadIdx.x == 0) {
+        out[slot0 + i] = a;
+        if (host_mirror) host_mirror[slot0 + i] = a;   // pinned, device-visible: no copy kernel for the read-back
+    }
 }
 
 // w -= sum_i h[i] V_i ; partial[blk] = sum w^2 over the block
@@ -612,6 +634,43 @@ __global__ void __launch_bounds__(NT) k_fill_phi(int n_nodes, double val, double
         z[(size_t)4 * n + 2] = 0.0;
         z[(size_t)4 * n + 3] = val;
     }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Deflation of partition-cut near-null modes (constants of a potential block on one connected
+// component): s_c = sum of the potential entries of r over nodes of mode c ; z += Z Einv s
+// ------------------------------------------------------------------------------------------
+template <int G>
+__global__ void __launch_bounds__(NT)
+k_defl_sums(int n_nodes, int c0, int m, const int32_t* __restrict__ node_mode, const double* __restrict__ r,
+            double* __restrict__ partial) {
+    __shared__ double sm[NT / 64];
+    double acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = 0.0;
+    for (int n = blockIdx.x * NT + threadIdx.x; n < n_nodes; n += gridDim.x * NT) {
+        const int md = node_mode[n];
+        const double v = r[(size_t)4 * n + 3];
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc[g] += (md == c0 + g) ? v : 0.0;
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        double t = block_sum(acc[g], sm);
+        if (threadIdx.x == 0 && c0 + g < m) partial[(size_t)(c0 + g) * RED_BLOCKS + blockIdx.x] = t;
+    }
+}
+__global__ void __launch_bounds__(NT)
+k_defl_add(int n_nodes, int m, const int32_t* __restrict__ node_mode, const double* __restrict__ einv,
+           const double* __restrict__ s, double* __restrict__ z) {
+    const int n = blockIdx.x * NT + threadIdx.x;
+    if (n >= n_nodes) return;
+    const int md = node_mode[n];
+    if (md < 0) return;
+    double y = 0.0;
+    for (int c = 0; c < m; ++c) y += einv[md * m + c] * s[c];
+    z[(size_t)4 * n + 3] += y;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -701,34 +760,49 @@ k_vbj_apply(int n_nodes_owned, const uint8_t* __restrict__ node_side, const int3
 // ------------------------------------------------------------------------------------------
 // AMG pieces
 // ------------------------------------------------------------------------------------------
-// d = c1*d + c2 * Dinv*(b - A x)     (L lanes per row); FIRST: x == 0, d = c2*Dinv*b
+// One Chebyshev step with the solution update fused (ping-pong buffers xin -> xout):
+//   d = c1*d + c2 * Dinv*(b - A xin) ;  xout = xin + d          (L lanes per row)
 template <int L>
 __global__ void __launch_bounds__(NT)
 k_cheby_step(int n_rows, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci, const double* __restrict__ v,
-             const double* __restrict__ dinv, const double* __restrict__ b, const double* __restrict__ x,
-             double c1, double c2, double* __restrict__ d) {
+             const double* __restrict__ dinv, const double* __restrict__ b, const double* __restrict__ xin,
+             double c1, double c2, double* __restrict__ d, double* __restrict__ xout) {
     const int gid = blockIdx.x * NT + threadIdx.x;
     const int row = gid / L;
     const int lane = threadIdx.x & (L - 1);
     double s = 0.0;
     if (row < n_rows) {
         const int e = rp[row + 1];
-        for (int k = rp[row] + lane; k < e; k += L) s += v[k] * x[ci[k]];
+        for (int k = rp[row] + lane; k < e; k += L) s += v[k] * xin[ci[k]];
     }
 #pragma unroll
     for (int o = L >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, L);
-    if (lane == 0 && row < n_rows) d[row] = (c1 != 0.0 ? c1 * d[row] : 0.0) + c2 * dinv[row] * (b[row] - s);
+    if (lane == 0 && row < n_rows) {
+        const double dn = (c1 != 0.0 ? c1 * d[row] : 0.0) + c2 * dinv[row] * (b[row] - s);
+        d[row] = dn;
+        xout[row] = xin[row] + dn;
+    }
 }
 static void launch_cheby(hipStream_t st, int lanes, int n_rows, const int32_t* rp, const int32_t* ci, const double* v,
-                         const double* dinv, const double* b, const double* x, double c1, double c2, double* d) {
+                         const double* dinv, const double* b, const double* xin, double c1, double c2, double* d, double* xout) {
     if (n_rows <= 0) return;
     switch (lanes) {
-        case 2: hipLaunchKernelGGL((k_cheby_step<2>), dim3(nblocks((int64_t)n_rows * 2)), dim3(NT), 0, st, n_rows, rp, ci, v, dinv, b, x, c1, c2, d); break;
-        case 4: hipLaunchKernelGGL((k_cheby_step<4>), dim3(nblocks((int64_t)n_rows * 4)), dim3(NT), 0, st, n_rows, rp, ci, v, dinv, b, x, c1, c2, d); break;
-        case 8: hipLaunchKernelGGL((k_cheby_step<8>), dim3(nblocks((int64_t)n_rows * 8)), dim3(NT), 0, st, n_rows, rp, ci, v, dinv, b, x, c1, c2, d); break;
-        case 16: hipLaunchKernelGGL((k_cheby_step<16>), dim3(nblocks((int64_t)n_rows * 16)), dim3(NT), 0, st, n_rows, rp, ci, v, dinv, b, x, c1, c2, d); break;
-        case 32: hipLaunchKernelGGL((k_cheby_step<32>), dim3(nblocks((int64_t)n_rows * 32)), dim3(NT), 0, st, n_rows, rp, ci, v, dinv, b, x, c1, c2, d); break;
-        default: hipLaunchKernelGGL((k_cheby_step<64>), dim3(nblocks((int64_t)n_rows * 64)), dim3(NT), 0, st, n_rows, rp, ci, v, dinv, b, x, c1, c2, d); break;
+        case 2: hipLaunchKernelGGL((k_cheby_step<2>), dim3(nblocks((int64_t)n_rows * 2)), dim3(NT), 0, st, n_rows, rp, ci, v, dinv, b, xin, c1, c2, d, xout); break;
+        case 4: hipLaunchKernelGGL((k_cheby_step<4>), dim3(nblocks((int64_t)n_rows * 4)), dim3(NT), 0, st, n_rows, rp, ci, v, dinv, b, xin, c1, c2, d, xout); break;
+        case 8: hipLaunchKernelGGL((k_cheby_step<8>), dim3(nblocks((int64_t)n_rows * 8)), dim3(NT), 0, st, n_rows, rp, ci, v, dinv, b, xin, c1, c2, d, xout); break;
+        case 16: hipLaunchKernelGGL((k_cheby_step<16>), dim3(nblocks((int64_t)n_rows * 16)), dim3(NT), 0, st, n_rows, rp, ci, v, dinv, b, xin, c1, c2, d, xout); break;
+        case 32: hipLaunchKernelGGL((k_cheby_step<32>), dim3(nblocks((int64_t)n_rows * 32)), dim3(NT), 0, st, n_rows, rp, ci, v, dinv, b, xin, c1, c2, d, xout); break;
+        default: hipLaunchKernelGGL((k_cheby_step<64>), dim3(nblocks((int64_t)n_rows * 64)), dim3(NT), 0, st, n_rows, rp, ci, v, dinv, b, xin, c1, c2, d, xout); break;
+    }
+}
+// first Chebyshev step from a zero guess: d = x = c * Dinv * b
+__global__ void __launch_bounds__(NT) k_cheby_first(int n, double c, const double* __restrict__ dinv,
+                                                    const double* __restrict__ b, double* __restrict__ d,
+                                                    double* __restrict__ x) {
+    for (int e = blockIdx.x * NT + threadIdx.x; e < n; e += gridDim.x * NT) {
+        const double t = c * dinv[e] * b[e];
+        d[e] = t;
+        x[e] = t;
     }
 }
 // y = M x, dense row-major n x n, one wave per row
@@ -1021,7 +1095,9 @@ int knp_create(knp_ctx** out, const knp_mesh_desc* mesh) {
     HIPCHK(hipMalloc((void**)&ctx->d_partial, (size_t)RED_SLOTS * RED_BLOCKS * sizeof(double)));
     HIPCHK(hipMalloc((void**)&ctx->d_red, RED_SLOTS * sizeof(double)));
     HIPCHK(hipMemset(ctx->d_red, 0, RED_SLOTS * sizeof(double)));
-    HIPCHK(hipHostMalloc((void**)&ctx->h_red, RED_SLOTS * sizeof(double)));
+    HIPCHK(hipHostMalloc((void**)&ctx->h_red, RED_SLOTS * sizeof(double), hipHostMallocMapped));
+    if (hipHostGetDevicePointer((void**)&ctx->h_red_dev, ctx->h_red, 0) != hipSuccess) ctx->h_red_dev = nullptr;
+    HIPCHK(hipMalloc((void**)&ctx->d_defl_einv, DEFL_MAX * DEFL_MAX * sizeof(double)));
     HIPCHK(hipMalloc((void**)&ctx->d_y, RED_SLOTS * sizeof(double)));
     HIPCHK(hipMalloc((void**)&ctx->d_vbj, std::max<size_t>((size_t)16 * g.n_nodes_owned, 1) * sizeof(double)));
     ctx->n_red_blocks = std::min(RED_BLOCKS, nblocks(ctx->n_dof_owned));
@@ -1056,9 +1132,10 @@ int knp_destroy(knp_ctx* ctx) {
         KnpAmgLevel& L = ctx->amg[l];
         dev_free(L.A_rp); dev_free(L.A_ci); dev_free(L.A_v); dev_free(L.inv_diag);
         dev_free(L.P_rp); dev_free(L.P_ci); dev_free(L.P_v); dev_free(L.R_rp); dev_free(L.R_ci); dev_free(L.R_v);
-        dev_free(L.x); dev_free(L.b); dev_free(L.r); dev_free(L.d);
+        dev_free(L.x); dev_free(L.b); dev_free(L.r); dev_free(L.d); dev_free(L.r2);
     }
     dev_free(ctx->d_amg_cinv);
+    dev_free(ctx->d_defl_mode); dev_free(ctx->d_defl_einv);
     delete ctx;
     return KNP_OK;
 }
@@ -1071,6 +1148,7 @@ int knp_set_stream(knp_ctx* ctx, void* s) {
 int knp_set_comm(knp_ctx* ctx, knp_halo_fn halo, knp_allreduce_fn ar, void* user) {
     CHECK_CTX(ctx);
     ctx->halo = halo; ctx->allreduce = ar; ctx->comm_user = user;
+    ctx->phi_count_cached = -1;
     return KNP_OK;
 }
 
@@ -1232,12 +1310,12 @@ int knp_assemble_matrix(knp_ctx* ctx, const knp_fields* fields) {
                            ctx->d_contrib_ptr, ctx->d_contrib_cell, ctx->d_contrib_k, ctx->d_cbar, ctx->d_rowptr, ctx->d_vals);
     if (g.n_g > 0) {
         if (g.dim == 2)
-            hipLaunchKernelGGL((k_gamma_facets<2, true, false>), dim3(nblocks(g.n_g)), dim3(NT), 0, ctx->stream, g.n_g, g.n_q, P,
+            hipLaunchKernelGGL((k_gamma_facets<2, true, false, 8>), dim3(nblocks((int64_t)g.n_g * 8)), dim3(NT), 0, ctx->stream, g.n_g, g.n_q, P,
                                ctx->d_fv, ctx->d_fmeas, ctx->d_qp, ctx->d_qw, f, 0, ctx->d_coords, ctx->d_gamma_prog,
                                (const int32_t* const*)nullptr, (const int32_t*)nullptr, (const double* const*)nullptr,
                                ctx->d_fmat, ctx->d_fvec);
         else
-            hipLaunchKernelGGL((k_gamma_facets<3, true, false>), dim3(nblocks(g.n_g)), dim3(NT), 0, ctx->stream, g.n_g, g.n_q, P,
+            hipLaunchKernelGGL((k_gamma_facets<3, true, false, 32>), dim3(nblocks((int64_t)g.n_g * 32)), dim3(NT), 0, ctx->stream, g.n_g, g.n_q, P,
                                ctx->d_fv, ctx->d_fmeas, ctx->d_qp, ctx->d_qw, f, 0, ctx->d_coords, ctx->d_gamma_prog,
                                (const int32_t* const*)nullptr, (const int32_t*)nullptr, (const double* const*)nullptr,
                                ctx->d_fmat, ctx->d_fvec);
@@ -1303,12 +1381,12 @@ int knp_assemble_rhs(knp_ctx* ctx, const knp_fields* fields, double* b) {
     ProfScope ps(ctx, 3);
     if (g.n_g > 0) {
         if (g.dim == 2)
-            hipLaunchKernelGGL((k_gamma_facets<2, false, true>), dim3(nblocks(g.n_g)), dim3(NT), 0, ctx->stream, g.n_g, g.n_q, P,
+            hipLaunchKernelGGL((k_gamma_facets<2, false, true, 8>), dim3(nblocks((int64_t)g.n_g * 8)), dim3(NT), 0, ctx->stream, g.n_g, g.n_q, P,
                                ctx->d_fv, ctx->d_fmeas, ctx->d_qp, ctx->d_qw, f, n_aux, ctx->d_coords, ctx->d_gamma_prog,
                                (const int32_t* const*)ctx->d_prog_code, (const int32_t*)ctx->d_prog_len,
                                (const double* const*)ctx->d_prog_consts, ctx->d_fmat, ctx->d_fvec);
         else
-            hipLaunchKernelGGL((k_gamma_facets<3, false, true>), dim3(nblocks(g.n_g)), dim3(NT), 0, ctx->stream, g.n_g, g.n_q, P,
+            hipLaunchKernelGGL((k_gamma_facets<3, false, true, 32>), dim3(nblocks((int64_t)g.n_g * 32)), dim3(NT), 0, ctx->stream, g.n_g, g.n_q, P,
                                ctx->d_fv, ctx->d_fmeas, ctx->d_qp, ctx->d_qw, f, n_aux, ctx->d_coords, ctx->d_gamma_prog,
                                (const int32_t* const*)ctx->d_prog_code, (const int32_t*)ctx->d_prog_len,
                                (const double* const*)ctx->d_prog_consts, ctx->d_fmat, ctx->d_fvec);
@@ -1343,25 +1421,28 @@ static int halo_update(knp_ctx* ctx, double* x) {
 static int dot_to_slot(knp_ctx* ctx, const double* a, const double* b, int slot) {
     const int nb = ctx->n_red_blocks;
     hipLaunchKernelGGL(k_dot, dim3(nb), dim3(NT), 0, ctx->stream, ctx->n_dof_owned, a, b, ctx->d_partial);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(NT), 0, ctx->stream, nb, ctx->d_partial, ctx->d_red, slot);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(NT), 0, ctx->stream, nb, ctx->d_partial, ctx->d_red, slot, ctx->mirror());
     return allreduce_slots(ctx, slot, 1);
 }
 static int read_slots(knp_ctx* ctx, int slot0, int count) {
-    HIPCHK(hipMemcpyAsync(ctx->h_red + slot0, ctx->d_red + slot0, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->allreduce || !ctx->h_red_dev)   // reduced over ranks in d_red: fetch; else the kernel already wrote the mirror
+        HIPCHK(hipMemcpyAsync(ctx->h_red + slot0, ctx->d_red + slot0, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return KNP_OK;
 }
 
 static int64_t global_phi_count(knp_ctx* ctx, int* rc) {
-    // number of potential DoFs over all ranks (uses slot 63)
+    // number of potential DoFs over all ranks (uses slot 63); cached (collective on first use)
     *rc = KNP_OK;
+    if (ctx->phi_count_cached >= 0) return ctx->phi_count_cached;
     double v = (double)ctx->g.n_nodes_owned;
     if (hipMemcpyAsync(ctx->d_red + 63, &v, sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { *rc = KNP_E_HIP; return 0; }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) { *rc = KNP_E_HIP; return 0; }
     *rc = allreduce_slots(ctx, 63, 1);
     if (*rc != KNP_OK) return 0;
-    *rc = read_slots(ctx, 63, 1);
-    return (int64_t)llround(ctx->h_red[63]);
+    if (hipMemcpy(ctx->h_red + 63, ctx->d_red + 63, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { *rc = KNP_E_HIP; return 0; }
+    ctx->phi_count_cached = (int64_t)llround(ctx->h_red[63]);
+    return ctx->phi_count_cached;
 }
 
 int knp_set_nullspace(knp_ctx* ctx, int32_t on) {
@@ -1378,7 +1459,7 @@ static int project_ns(knp_ctx* ctx, double* v) {
     const int no = ctx->g.n_nodes_owned;
     const int nb = std::min(RED_BLOCKS, nblocks(no));
     hipLaunchKernelGGL(k_phi_sum, dim3(nb), dim3(NT), 0, ctx->stream, no, v, ctx->d_partial);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(NT), 0, ctx->stream, nb, ctx->d_partial, ctx->d_red, 62);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(NT), 0, ctx->stream, nb, ctx->d_partial, ctx->d_red, 62, (double*)nullptr);
     KCHK(allreduce_slots(ctx, 62, 1));
     hipLaunchKernelGGL(k_phi_sub, dim3(nblocks(no)), dim3(NT), 0, ctx->stream, no, ctx->d_red + 62, 1.0 / (double)cnt, v);
     HIPCHK(hipGetLastError());
@@ -1413,9 +1494,9 @@ static int spmv_A(knp_ctx* ctx, double* x, const double* b, double* y, bool resi
     ProfScope ps(ctx, 0);
     const int lanes = pick_lanes(ctx->n_dof_owned ? (double)ctx->nnz / ctx->n_dof_owned : 1.0);
     if (residual)
-        launch_spmv<1>(ctx->stream, lanes, ctx->n_dof_owned, ctx->d_rowptr, ctx->d_colind, ctx->d_vals, x, b, y);
+        launch_spmv<1, 1>(ctx->stream, lanes, ctx->n_dof_owned, ctx->d_rowptr, ctx->d_colind, ctx->d_vals, x, b, y);
     else
-        launch_spmv<0>(ctx->stream, lanes, ctx->n_dof_owned, ctx->d_rowptr, ctx->d_colind, ctx->d_vals, x, b, y);
+        launch_spmv<0, 1>(ctx->stream, lanes, ctx->n_dof_owned, ctx->d_rowptr, ctx->d_colind, ctx->d_vals, x, b, y);
     HIPCHK(hipGetLastError());
     return KNP_OK;
 }
@@ -1453,7 +1534,7 @@ int knp_amg_reset(knp_ctx* ctx, int32_t n_levels, int32_t pre, int32_t post, int
         KnpAmgLevel& L = ctx->amg[l];
         dev_free(L.A_rp); dev_free(L.A_ci); dev_free(L.A_v); dev_free(L.inv_diag);
         dev_free(L.P_rp); dev_free(L.P_ci); dev_free(L.P_v); dev_free(L.R_rp); dev_free(L.R_ci); dev_free(L.R_v);
-        dev_free(L.x); dev_free(L.b); dev_free(L.r); dev_free(L.d);
+        dev_free(L.x); dev_free(L.b); dev_free(L.r); dev_free(L.d); dev_free(L.r2);
         L.n = L.n_coarse = 0;
     }
     dev_free(ctx->d_amg_cinv);
@@ -1499,6 +1580,8 @@ int knp_amg_set_level(knp_ctx* ctx, int32_t level, int32_t n_rows, int32_t n_col
     HIPCHK(hipMalloc((void**)&L.b, (size_t)n_rows * sizeof(double)));
     HIPCHK(hipMalloc((void**)&L.r, (size_t)n_rows * sizeof(double)));
     HIPCHK(hipMalloc((void**)&L.d, (size_t)n_rows * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&L.r2, (size_t)n_rows * sizeof(double)));
+    HIPCHK(hipMemset(L.r2, 0, (size_t)n_rows * sizeof(double)));
     HIPCHK(hipMemset(L.x, 0, (size_t)n_rows * sizeof(double)));
     HIPCHK(hipMemset(L.d, 0, (size_t)n_rows * sizeof(double)));
     return KNP_OK;
@@ -1512,58 +1595,77 @@ int knp_amg_set_coarse(knp_ctx* ctx, int32_t n, const double* inv) {
     return KNP_OK;
 }
 
-// Chebyshev smoothing of A x = b on one level; zero_guess: x == 0 on entry
-static void amg_smooth(knp_ctx* ctx, KnpAmgLevel& L, const double* b, double* x, bool zero_guess) {
+// Chebyshev smoothing sweep of A x = b on one level with ping-pong buffers.  On entry the iterate is in
+// *cur (ignored when zero_guess); the sweep alternates between bufA and bufB and leaves *cur pointing at
+// the buffer that holds the result.
+static void amg_smooth(knp_ctx* ctx, KnpAmgLevel& L, const double* b, double** cur, double* bufA, double* bufB, bool zero_guess) {
     const double lmax = 1.1 * L.lambda_max, lmin = 0.1 * L.lambda_max;  // smoothing interval [0.1, 1.1] * lambda_max
     const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
     const double sigma = theta / delta;
     double rho_old = 1.0 / sigma;
     const int deg = ctx->amg_cheby;
     hipStream_t st = ctx->stream;
-    const int nb = nblocks(L.n);
-    // step 0: d = Dinv (b - A x) / theta ; x += d
+    auto other = [&](double* p) { return p == bufA ? bufB : bufA; };
     if (zero_guess) {
-        hipLaunchKernelGGL(k_diag_scale, dim3(std::min(nb, 2048)), dim3(NT), 0, st, L.n, 1.0 / theta, L.inv_diag, b, L.d);
-        hipLaunchKernelGGL(k_diag_scale, dim3(std::min(nb, 2048)), dim3(NT), 0, st, L.n, 1.0 / theta, L.inv_diag, b, x);
+        hipLaunchKernelGGL(k_cheby_first, dim3(std::min(nblocks(L.n), 2048)), dim3(NT), 0, st, L.n, 1.0 / theta, L.inv_diag, b, L.d, *cur);
     } else {
-        launch_cheby(st, L.A_lanes, L.n, L.A_rp, L.A_ci, L.A_v, L.inv_diag, b, x, 0.0, 1.0 / theta, L.d);
-        hipLaunchKernelGGL(k_axpy, dim3(std::min(nb, 2048)), dim3(NT), 0, st, L.n, 1.0, L.d, x);
+        double* out = other(*cur);
+        launch_cheby(st, L.A_lanes, L.n, L.A_rp, L.A_ci, L.A_v, L.inv_diag, b, *cur, 0.0, 1.0 / theta, L.d, out);
+        *cur = out;
     }
     for (int k = 1; k < deg; ++k) {
         const double rho = 1.0 / (2.0 * sigma - rho_old);
-        launch_cheby(st, L.A_lanes, L.n, L.A_rp, L.A_ci, L.A_v, L.inv_diag, b, x, rho * rho_old, 2.0 * rho / delta, L.d);
-        hipLaunchKernelGGL(k_axpy, dim3(std::min(nb, 2048)), dim3(NT), 0, st, L.n, 1.0, L.d, x);
+        double* out = other(*cur);
+        launch_cheby(st, L.A_lanes, L.n, L.A_rp, L.A_ci, L.A_v, L.inv_diag, b, *cur, rho * rho_old, 2.0 * rho / delta, L.d, out);
+        *cur = out;
         rho_old = rho;
     }
 }
 
-static int amg_vcycle(knp_ctx* ctx, int l, const double* b, double* x) {
+// number of buffer flips one level performs (decides where to start so that the result lands in `want`)
+static int amg_flips(const knp_ctx* ctx, bool last_no_dense) {
+    const int deg = ctx->amg_cheby;
+    int sweeps = last_no_dense ? (ctx->amg_pre + ctx->amg_post) : 0;
+    if (last_no_dense) return sweeps > 0 ? (deg - 1) + (sweeps - 1) * deg : 0;
+    int f = 0;
+    if (ctx->amg_pre > 0) f += (deg - 1) + (ctx->amg_pre - 1) * deg;
+    f += ctx->amg_post * deg;
+    return f;
+}
+
+// V-cycle on level l for right-hand side b.  The result is written to `want` when non-null (level 0: the
+// caller's z), otherwise to whichever of the level's two buffers the ping-pong ends in; returns that pointer.
+static double* amg_vcycle(knp_ctx* ctx, int l, const double* b, double* want) {
     hipStream_t st = ctx->stream;
     KnpAmgLevel& L = ctx->amg[l];
     const bool last = (l == ctx->amg_levels - 1);
+    double* bufA = want ? want : L.x;
+    double* bufB = L.r2;
     if (last && ctx->amg_nc > 0) {
-        hipLaunchKernelGGL(k_dense_matvec, dim3(nblocks((int64_t)ctx->amg_nc * 64)), dim3(NT), 0, st, ctx->amg_nc, ctx->d_amg_cinv, b, x);
-        return KNP_OK;
+        hipLaunchKernelGGL(k_dense_matvec, dim3(nblocks((int64_t)ctx->amg_nc * 64)), dim3(NT), 0, st, ctx->amg_nc, ctx->d_amg_cinv, b, bufA);
+        return bufA;
     }
+    const int flips = amg_flips(ctx, last);
+    double* cur = (flips & 1) ? bufB : bufA;    // start so that the final iterate lands in bufA
     if (last) {  // no coarse inverse supplied: smooth only
-        amg_smooth(ctx, L, b, x, true);
-        for (int s = 1; s < ctx->amg_pre + ctx->amg_post; ++s) amg_smooth(ctx, L, b, x, false);
-        return KNP_OK;
+        bool zero = true;
+        for (int sw = 0; sw < ctx->amg_pre + ctx->amg_post; ++sw) { amg_smooth(ctx, L, b, &cur, bufA, bufB, zero); zero = false; }
+        if (zero) { hipLaunchKernelGGL(k_fill, dim3(std::min(nblocks(L.n), 2048)), dim3(NT), 0, st, L.n, 0.0, bufA); cur = bufA; }
+        return cur;
     }
     KnpAmgLevel& C = ctx->amg[l + 1];
     const int nc = L.n_coarse;
     bool zero = true;
-    for (int s = 0; s < ctx->amg_pre; ++s) { amg_smooth(ctx, L, b, x, zero); zero = false; }
-    if (zero) hipLaunchKernelGGL(k_fill, dim3(std::min(nblocks(L.n), 2048)), dim3(NT), 0, st, L.n, 0.0, x);
+    for (int sw = 0; sw < ctx->amg_pre; ++sw) { amg_smooth(ctx, L, b, &cur, bufA, bufB, zero); zero = false; }
+    if (zero) hipLaunchKernelGGL(k_fill, dim3(std::min(nblocks(L.n), 2048)), dim3(NT), 0, st, L.n, 0.0, cur);
     // r = b - A x ; b_c = R r
-    launch_spmv<1>(st, L.A_lanes, L.n, L.A_rp, L.A_ci, L.A_v, x, b, L.r);
+    launch_spmv<1>(st, L.A_lanes, L.n, L.A_rp, L.A_ci, L.A_v, cur, b, L.r);
     launch_spmv<0>(st, L.R_lanes, nc, L.R_rp, L.R_ci, L.R_v, L.r, nullptr, C.b);
-    KCHK(amg_vcycle(ctx, l + 1, C.b, C.x));
-    // x += P x_c   (r reused as temp)
-    launch_spmv<0>(st, L.P_lanes, L.n, L.P_rp, L.P_ci, L.P_v, C.x, nullptr, L.r);
-    hipLaunchKernelGGL(k_axpy, dim3(std::min(nblocks(L.n), 2048)), dim3(NT), 0, st, L.n, 1.0, L.r, x);
-    for (int s = 0; s < ctx->amg_post; ++s) amg_smooth(ctx, L, b, x, false);
-    return KNP_OK;
+    double* xc = amg_vcycle(ctx, l + 1, C.b, nullptr);
+    // x += P x_c (fused)
+    launch_spmv<2>(st, L.P_lanes, L.n, L.P_rp, L.P_ci, L.P_v, xc, nullptr, cur);
+    for (int sw = 0; sw < ctx->amg_post; ++sw) amg_smooth(ctx, L, b, &cur, bufA, bufB, false);
+    return cur;
 }
 
 int knp_pc_setup(knp_ctx* ctx, int32_t kind) {
@@ -1588,6 +1690,16 @@ int knp_pc_setup(knp_ctx* ctx, int32_t kind) {
 
 // z = M^{-1} r, then (optionally) gauge projection.  cnt = global number of potential DoFs.
 static int pc_apply_proj(knp_ctx* ctx, const double* r, double* z, int64_t cnt) {
+    const int dm = ctx->defl_m;
+    if (dm > 0) {   // coarse sums of the input residual (before r is possibly overwritten)
+        ProfScope ps(ctx, 4);
+        const int no = ctx->g.n_nodes_owned;
+        const int nb = std::min(RED_BLOCKS, nblocks(no));
+        for (int c0 = 0; c0 < dm; c0 += 8)
+            hipLaunchKernelGGL((k_defl_sums<8>), dim3(nb), dim3(NT), 0, ctx->stream, no, c0, dm, ctx->d_defl_mode, r, ctx->d_partial);
+        hipLaunchKernelGGL(k_reduce_partials, dim3(dm), dim3(NT), 0, ctx->stream, nb, ctx->d_partial, ctx->d_red, DEFL_SLOT0, (double*)nullptr);
+        KCHK(allreduce_slots(ctx, DEFL_SLOT0, dm));
+    }
     {
         ProfScope ps(ctx, 2);
         const KnpHostGraph& g = ctx->g;
@@ -1598,7 +1710,10 @@ static int pc_apply_proj(knp_ctx* ctx, const double* r, double* z, int64_t cnt) 
                                    ctx->d_node_side, ctx->d_node_gv, ctx->d_gv_node_e, ctx->d_vbj, r, z);
                 break;
             case KNP_PC_AMG:
-                KCHK(amg_vcycle(ctx, 0, r, z));
+                {
+                    double* out = amg_vcycle(ctx, 0, r, z);
+                    if (out != z) HIPCHK(hipMemcpyAsync(z, out, (size_t)ctx->n_dof_owned * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+                }
                 break;
             default:
                 HIPCHK(hipMemcpyAsync(z, r, (size_t)ctx->n_dof_owned * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
@@ -1606,16 +1721,38 @@ static int pc_apply_proj(knp_ctx* ctx, const double* r, double* z, int64_t cnt) 
         }
         HIPCHK(hipGetLastError());
     }
+    if (dm > 0) {
+        ProfScope ps(ctx, 4);
+        const int no = ctx->g.n_nodes_owned;
+        hipLaunchKernelGGL(k_defl_add, dim3(nblocks(no)), dim3(NT), 0, ctx->stream, no, dm, ctx->d_defl_mode, ctx->d_defl_einv,
+                           ctx->d_red + DEFL_SLOT0, z);
+    }
     if (ctx->ns_on && cnt > 0) {
         ProfScope ps(ctx, 4);
         const int no = ctx->g.n_nodes_owned;
         const int nb = std::min(RED_BLOCKS, nblocks(no));
         hipLaunchKernelGGL(k_phi_sum, dim3(nb), dim3(NT), 0, ctx->stream, no, z, ctx->d_partial);
-        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(NT), 0, ctx->stream, nb, ctx->d_partial, ctx->d_red, 62);
+        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(NT), 0, ctx->stream, nb, ctx->d_partial, ctx->d_red, 62, (double*)nullptr);
         KCHK(allreduce_slots(ctx, 62, 1));
         hipLaunchKernelGGL(k_phi_sub, dim3(nblocks(no)), dim3(NT), 0, ctx->stream, no, ctx->d_red + 62, 1.0 / (double)cnt, z);
         HIPCHK(hipGetLastError());
     }
+    return KNP_OK;
+}
+
+int knp_set_deflation(knp_ctx* ctx, int32_t n_modes, const int32_t* node_mode, const double* einv) {
+    CHECK_CTX(ctx);
+    if (n_modes < 0 || n_modes > DEFL_MAX || (n_modes > 0 && (!node_mode || !einv))) { ctx->err = "bad deflation arguments (at most 32 modes)"; return KNP_E_ARG; }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->defl_m = 0;
+    if (n_modes == 0) return KNP_OK;
+    const int no = ctx->g.n_nodes_owned;
+    for (int n = 0; n < no; ++n)
+        if (node_mode[n] < -1 || node_mode[n] >= n_modes) { ctx->err = "deflation mode id out of range"; return KNP_E_ARG; }
+    dev_free(ctx->d_defl_mode);
+    KCHK(dev_upload_raw(ctx, &ctx->d_defl_mode, node_mode, (size_t)no));
+    HIPCHK(hipMemcpy(ctx->d_defl_einv, einv, (size_t)n_modes * n_modes * sizeof(double), hipMemcpyHostToDevice));
+    ctx->defl_m = n_modes;
     return KNP_OK;
 }
 
@@ -1682,10 +1819,10 @@ int knp_gmres_solve(knp_ctx* ctx, const double* b, double* x, double rtol, doubl
                 ProfScope ps(ctx, 1);
                 for (int i0 = 0; i0 <= j; i0 += 8)
                     hipLaunchKernelGGL((k_multi_dot<8>), dim3(nb), dim3(NT), 0, st, n, ldv, i0, j + 1, ctx->d_V, ctx->d_w, ctx->d_partial);
-                hipLaunchKernelGGL(k_reduce_partials, dim3(j + 1), dim3(NT), 0, st, nb, ctx->d_partial, ctx->d_red, 0);
+                hipLaunchKernelGGL(k_reduce_partials, dim3(j + 1), dim3(NT), 0, st, nb, ctx->d_partial, ctx->d_red, 0, ctx->mirror());
                 KCHK(allreduce_slots(ctx, 0, j + 1));
                 hipLaunchKernelGGL(k_update_norm, dim3(nb), dim3(NT), 0, st, n, ldv, j + 1, ctx->d_V, ctx->d_red, ctx->d_w, ctx->d_partial);
-                hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(NT), 0, st, nb, ctx->d_partial, ctx->d_red, j + 1);
+                hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(NT), 0, st, nb, ctx->d_partial, ctx->d_red, j + 1, ctx->mirror());
                 KCHK(allreduce_slots(ctx, j + 1, 1));
                 if (j + 1 < m + 1)
                     hipLaunchKernelGGL(k_scale_rsqrt, dim3(std::min(nblocks(n), 2048)), dim3(NT), 0, st, n, ctx->d_w, ctx->d_red + j + 1,
@@ -1790,7 +1927,7 @@ int knp_l2_norms(knp_ctx* ctx, const double* phi_i, const double* phi_e, double*
         hipLaunchKernelGGL((k_l2<2>), dim3(nb), dim3(NT), 0, ctx->stream, g.n_c_owned, ctx->d_cells, ctx->d_cell_side, ctx->d_coords, phi_i, phi_e, ctx->d_partial);
     else
         hipLaunchKernelGGL((k_l2<3>), dim3(nb), dim3(NT), 0, ctx->stream, g.n_c_owned, ctx->d_cells, ctx->d_cell_side, ctx->d_coords, phi_i, phi_e, ctx->d_partial);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(2), dim3(NT), 0, ctx->stream, nb, ctx->d_partial, ctx->d_red, 58);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(2), dim3(NT), 0, ctx->stream, nb, ctx->d_partial, ctx->d_red, 58, ctx->mirror());
     HIPCHK(hipGetLastError());
     KCHK(read_slots(ctx, 58, 2));
     out[0] = ctx->h_red[58];

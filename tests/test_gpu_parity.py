@@ -158,10 +158,31 @@ def test_two_steps_match_oracle(pc):
     for j in range(3):
         vi = o.lay.node_i >= 0
         ve = o.lay.node_e >= 0
-        assert np.allclose(s.problem.wh[0][j].numpy()[vi], o.k[0][j][vi], rtol=1e-9)
-        assert np.allclose(s.problem.wh[1][j].numpy()[ve], o.k[1][j][ve], rtol=1e-9)
+        # the preconditioned-residual stopping rule (reference: ksp_norm_type preconditioned) bounds the
+        # concentration error only up to the non-normality of P^-1 A (||P_kk^-1 A_kphi|| ~ c/psi ~ 4e3)
+        assert np.allclose(s.problem.wh[0][j].numpy()[vi], o.k[0][j][vi], rtol=1e-7)
+        assert np.allclose(s.problem.wh[1][j].numpy()[ve], o.k[1][j][ve], rtol=1e-7)
     if pc == "hypre":
         assert abs(ne - oe) <= 1e-4 * oe
+
+
+@pytest.mark.parametrize("N,kind,steps", [(32, "square", 3), (8, "cube", 2)])
+def test_gmres_amg_iterates_match_oracle_gmres(N, kind, steps):
+    """Same algorithm on both sides: the oracle's PETSc-style GMRES(30) with the NumPy V-cycle applied to the
+    *same* hierarchy data must take the same number of iterations and land on the same iterate."""
+    import knpemi_oracle as K
+    cfg = ci_config(N=N, steps=steps, rtol=1e-9, kind=kind)
+    cfg["solver"]["ksp_settings"]["amg_coarse_size"] = 200      # force a real multilevel cycle on this small mesh
+    s = run_native(cfg)
+    h = s.hierarchy
+    assert len(h.levels) >= 2
+    o = make_oracle(N, kind)
+    xo, its = o.run(steps, solver="gmres", rtol=1e-9,
+                    pc=lambda P: K.pc_amg_vcycle(h.levels, h.coarse_inv, s.amg_pre, s.amg_post, s.amg_cheby_degree))
+    assert its == list(s.iterations)
+    x = s.backend.x.cpu().numpy()
+    for f in range(4):
+        assert np.max(np.abs(x[f::4] - xo[f::4])) <= 1e-9 * np.max(np.abs(xo[f::4])), f
 
 
 def test_ci_problem_against_reference_pins():
