@@ -74,7 +74,9 @@ extern "C" {
 /* preconditioner kinds */
 #define KNP_PC_NONE 0
 #define KNP_PC_VBJACOBI 1 /* per-vertex 4x4 / 8x8 blocks of A, refreshed with A */
-#define KNP_PC_AMG 2      /* multilevel V-cycle on P (levels supplied with knp_amg_*) */
+#define KNP_PC_AMG 2      /* multilevel V-cycle on P, hierarchy 0 = all fields (the reference's block-Jacobi form) */
+#define KNP_PC_AMG_BT 3   /* block lower-triangular: hierarchy 0 = ion fields, then the potential (hierarchy 1) on
+                             r_phi - A_{phi,k} z_k with a Cahouet-Chabard Schur term psi/(sum z^2 k)/M_lumped added */
 
 /* membrane-program opcodes: instruction = {op, dst, a, b}, registers are doubles */
 enum {
@@ -182,15 +184,19 @@ int knp_pc_apply(knp_ctx* ctx, const double* r, double* z);
  * vectors of the potential DoFs of each mode. node_mode: host [n_nodes_owned], -1 = not deflated.
  * Einv: host [n_modes^2] (pseudo-)inverse of Z^T A Z, identical on every rank. n_modes = 0 disables. */
 int knp_set_deflation(knp_ctx* ctx, int32_t n_modes, const int32_t* node_mode, const double* einv);
-/* AMG hierarchy supplied level by level (level 0 = finest = P itself). All arrays HOST; copied. */
-int knp_amg_reset(knp_ctx* ctx, int32_t n_levels, int32_t pre_sweeps, int32_t post_sweeps, int32_t cheby_degree);
-int knp_amg_set_level(knp_ctx* ctx, int32_t level, int32_t n_rows, int32_t n_cols_halo,
+/* AMG hierarchies (hier 0 or 1) supplied level by level (level 0 = finest = P itself, possibly restricted to a
+ * field class by zero rows). All arrays HOST; copied. */
+int knp_amg_reset(knp_ctx* ctx, int32_t hier, int32_t n_levels, int32_t pre_sweeps, int32_t post_sweeps, int32_t cheby_degree);
+int knp_amg_set_level(knp_ctx* ctx, int32_t hier, int32_t level, int32_t n_rows, int32_t n_cols_halo,
                       const int32_t* A_rowptr, const int32_t* A_colind, const double* A_vals,
                       const double* inv_diag, double lambda_max,
                       int32_t n_coarse,
                       const int32_t* P_rowptr, const int32_t* P_colind, const double* P_vals,
                       const int32_t* R_rowptr, const int32_t* R_colind, const double* R_vals);
-int knp_amg_set_coarse(knp_ctx* ctx, int32_t n, const double* dense_inverse /* host [n*n] row-major */);
+int knp_amg_set_coarse(knp_ctx* ctx, int32_t hier, int32_t n, const double* dense_inverse /* host [n*n] row-major */);
+/* level 0 == the library's own P (owned block): use its pair-major storage and node kernels instead of the uploaded
+ * CSR. mode: 0 off, 1 all four fields, 2 ion fields only, 3 potential only */
+int knp_amg_use_native_level0(knp_ctx* ctx, int32_t hier, int32_t mode);
 int knp_gmres_solve(knp_ctx* ctx, const double* b, double* x, double rtol, double atol, int32_t max_it,
                     int32_t restart, int32_t* its, double* rnorm, int32_t* reason);
 

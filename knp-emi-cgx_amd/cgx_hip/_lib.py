@@ -18,7 +18,7 @@ KNP_SZ_COUNT = 16
 (SZ_N_NODES, SZ_N_NODES_OWNED, SZ_N_DOF_LOCAL, SZ_N_DOF_OWNED, SZ_NNZ, SZ_N_PAIRS, SZ_N_CONTRIB,
  SZ_N_GAMMA_VERTS, SZ_N_GAMMA_PAIRS, SZ_NNZ_P, SZ_N_PHI_OWNED) = range(11)
 
-PC_NONE, PC_VBJACOBI, PC_AMG = 0, 1, 2
+PC_NONE, PC_VBJACOBI, PC_AMG, PC_AMG_BT = 0, 1, 2, 3
 
 OPS = dict(CONST=0, KI=1, KE=2, PHIM=3, AUX=4, X=5, ADD=6, SUB=7, MUL=8, DIV=9, NEG=10, POW=11, LN=12,
            EXP=13, SQRT=14, MAX=15, MIN=16, ABS=17, LT=18, GT=19, LE=20, GE=21, EQ=22, AND=23, OR=24,
@@ -79,10 +79,11 @@ SIGNATURES = {
     "knp_pc_setup": (C.c_int, [vp, C.c_int32]),
     "knp_pc_apply": (C.c_int, [vp, vp, vp]),
     "knp_set_deflation": (C.c_int, [vp, C.c_int32, i32p, f64p]),
-    "knp_amg_reset": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
-    "knp_amg_set_level": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, i32p, i32p, f64p, f64p, C.c_double,
+    "knp_amg_reset": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "knp_amg_set_level": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, i32p, i32p, f64p, f64p, C.c_double,
                                     C.c_int32, i32p, i32p, f64p, i32p, i32p, f64p]),
-    "knp_amg_set_coarse": (C.c_int, [vp, C.c_int32, f64p]),
+    "knp_amg_set_coarse": (C.c_int, [vp, C.c_int32, C.c_int32, f64p]),
+    "knp_amg_use_native_level0": (C.c_int, [vp, C.c_int32, C.c_int32]),
     "knp_gmres_solve": (C.c_int, [vp, vp, vp, C.c_double, C.c_double, C.c_int32, C.c_int32, i32p, f64p, i32p]),
     "knp_pack": (C.c_int, [vp, C.POINTER(FieldsOut), vp]),
     "knp_unpack": (C.c_int, [vp, vp, C.POINTER(FieldsOut)]),

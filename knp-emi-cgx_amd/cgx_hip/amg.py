@@ -125,8 +125,21 @@ class Hierarchy:
                 "grid_complexity": float(sum(rows)) / max(rows[0], 1)}
 
 
+def restrict_to_fields(P: sp.csr_matrix, fields, block: int = 4) -> sp.csr_matrix:
+    """P with the rows and columns of all other fields zeroed (same size): the level-0 operator of a
+    hierarchy that only acts on one field class (ions: (0,1,2); potential: (3,))."""
+    n = P.shape[0]
+    keep = np.isin(np.arange(n) % block, fields).astype(np.float64)
+    D = sp.diags(keep)
+    out = (D @ P @ D).tocsr()
+    out.eliminate_zeros()
+    return out
+
+
 def build_hierarchy(P: sp.csr_matrix, theta: float = 0.08, max_levels: int = 12, coarse_size: int = 2500,
                     smooth_prolongator: bool = True) -> Hierarchy:
+    """Rows with a zero diagonal are inactive: they get no aggregate (zero rows in the prolongator, zero inverse
+    diagonal in the smoother), so a field-restricted P yields a hierarchy of that field class only."""
     A = sp.csr_matrix(P, dtype=np.float64)
     A.sort_indices()
     levels = []
@@ -135,15 +148,24 @@ def build_hierarchy(P: sp.csr_matrix, theta: float = 0.08, max_levels: int = 12,
         dinv = np.where(diag != 0.0, 1.0 / np.where(diag != 0.0, diag, 1.0), 0.0)
         lam = estimate_lambda_max(A, dinv)
         n = A.shape[0]
-        if n <= coarse_size or len(levels) >= max_levels - 1:
+        if int((diag != 0.0).sum()) <= coarse_size or len(levels) >= max_levels - 1:
             levels.append(Level(A, dinv, lam))
             break
-        S = strength_graph(A, theta)
-        agg, nagg = aggregate(S, seed=len(levels))
-        if nagg >= 0.9 * n:                                   # coarsening stalled
+        # strength threshold decays with the level (Galerkin operators of smoothed aggregation get denser and
+        # their entries more uniform; a fixed threshold stalls the coarsening in 3D)
+        S = strength_graph(A, theta * 0.25 ** len(levels))
+        active = diag != 0.0
+        if active.all():
+            agg, nagg = aggregate(S, seed=len(levels))
+            rows_t = np.arange(n)
+        else:
+            ia = np.nonzero(active)[0]
+            agg, nagg = aggregate(S[ia][:, ia].tocsr(), seed=len(levels))
+            rows_t = ia
+        if nagg >= 0.9 * rows_t.size:                         # coarsening stalled
             levels.append(Level(A, dinv, lam))
             break
-        T = sp.csr_matrix((np.ones(n), (np.arange(n), agg)), shape=(n, nagg))
+        T = sp.csr_matrix((np.ones(rows_t.size), (rows_t, agg)), shape=(n, nagg))
         if smooth_prolongator:
             # filtered matrix: weak off-diagonals lumped onto the diagonal
             Sp = S + sp.identity(n, format="csr")
@@ -164,15 +186,14 @@ def build_hierarchy(P: sp.csr_matrix, theta: float = 0.08, max_levels: int = 12,
         Ac.sort_indices()
         levels.append(Level(A, dinv, lam, Pm, R))
         A = Ac
-    Ad = levels[-1].A.toarray()
-    if Ad.shape[0] <= 4000:
-        coarse_inv = np.linalg.pinv(Ad, rcond=1e-13)
+    if levels[-1].A.shape[0] <= 6000:
+        coarse_inv = np.linalg.pinv(levels[-1].A.toarray(), rcond=1e-13)
     else:
         coarse_inv = None
     return Hierarchy(levels, coarse_inv)
 
 
-def upload(lib, ctx, check, hier: Hierarchy, pre: int = 1, post: int = 1, cheby_degree: int = 2):
+def upload(lib, ctx, check, hier: Hierarchy, pre: int = 1, post: int = 1, cheby_degree: int = 2, index: int = 0):
     """Hand the hierarchy to libknpemi_hip (host arrays are copied by the library)."""
     import ctypes as C
     i32p = C.POINTER(C.c_int32)
@@ -185,7 +206,7 @@ def upload(lib, ctx, check, hier: Hierarchy, pre: int = 1, post: int = 1, cheby_
         return a.ctypes.data_as(f64p)
 
     nl = len(hier.levels)
-    check(lib.knp_amg_reset(ctx, nl, pre, post, cheby_degree))
+    check(lib.knp_amg_reset(ctx, index, nl, pre, post, cheby_degree))
     keep = []
     for l, lv in enumerate(hier.levels):
         A = lv.A
@@ -202,12 +223,12 @@ def upload(lib, ctx, check, hier: Hierarchy, pre: int = 1, post: int = 1, cheby_
             Rci = np.ascontiguousarray(lv.R.indices, dtype=np.int32)
             Rv = np.ascontiguousarray(lv.R.data, dtype=np.float64)
             keep += [Prp, Pci, Pv, Rrp, Rci, Rv]
-            check(lib.knp_amg_set_level(ctx, l, A.shape[0], A.shape[0], ip(rp), ip(ci), fp(va), fp(dinv),
+            check(lib.knp_amg_set_level(ctx, index, l, A.shape[0], A.shape[0], ip(rp), ip(ci), fp(va), fp(dinv),
                                         float(lv.lambda_max), lv.P.shape[1], ip(Prp), ip(Pci), fp(Pv),
                                         ip(Rrp), ip(Rci), fp(Rv)))
         else:
-            check(lib.knp_amg_set_level(ctx, l, A.shape[0], A.shape[0], ip(rp), ip(ci), fp(va), fp(dinv),
+            check(lib.knp_amg_set_level(ctx, index, l, A.shape[0], A.shape[0], ip(rp), ip(ci), fp(va), fp(dinv),
                                         float(lv.lambda_max), 0, None, None, None, None, None, None))
     if hier.coarse_inv is not None:
         ci_ = np.ascontiguousarray(hier.coarse_inv, dtype=np.float64)
-        check(lib.knp_amg_set_coarse(ctx, ci_.shape[0], fp(ci_)))
+        check(lib.knp_amg_set_coarse(ctx, index, ci_.shape[0], fp(ci_)))

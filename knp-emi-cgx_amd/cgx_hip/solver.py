@@ -10,6 +10,10 @@ Linear solver mapping (reference :211-214, 269-280):
                               Gram-Schmidt, preconditioned norm, non-zero initial guess
   pc_type  hypre           -> smoothed-aggregation AMG V-cycle on the block-diagonal P (cgx_hip/amg.py
                               + HIP V-cycle), the native stand-in for BoomerAMG
+  pc_type  btcc            -> block lower-triangular variant: AMG on the ion blocks of P, then AMG on the
+                              potential block applied to r_phi - A_{phi,k} z_k plus a Cahouet-Chabard Schur
+                              term; keeps iteration counts mesh independent in 3D where the block-Jacobi
+                              form does not ("Preconditioners")
   pc_type  bjacobi|vbjacobi-> per-vertex 4x4 / 8x8 block Jacobi of A (HIP)
   pc_type  none            -> unpreconditioned
   direct: True             -> MUMPS has no native counterpart; emulated by GMRES+AMG driven to
@@ -109,8 +113,8 @@ class SolverKNPEMI:
                 if k in ks: setattr(self, k, type(getattr(self, k))(ks[k]))
         if self.ksp_type != "gmres":
             raise NotImplementedError(f"ksp_type '{self.ksp_type}': only 'gmres' is implemented natively.")
-        if self.pc_type not in ("hypre", "amg", "bjacobi", "vbjacobi", "none"):
-            raise NotImplementedError(f"pc_type '{self.pc_type}' has no native counterpart (hypre|amg|bjacobi|vbjacobi|none).")
+        if self.pc_type not in ("hypre", "amg", "btcc", "bjacobi", "vbjacobi", "none"):
+            raise NotImplementedError(f"pc_type '{self.pc_type}' has no native counterpart (hypre|amg|btcc|bjacobi|vbjacobi|none).")
         if self.norm_type != "preconditioned":
             raise NotImplementedError("only norm_type 'preconditioned' is implemented (reference default).")
         if self.save_mat:
@@ -135,14 +139,26 @@ class SolverKNPEMI:
         self.print("Assembling preconditioner ...")
         be = self.backend
         be.assemble_precond()
-        if self._pc_kind == _lib.PC_AMG:
+        if self._pc_kind in (_lib.PC_AMG, _lib.PC_AMG_BT):
             tic = time.perf_counter()
             P = be.precond_csr()
             P = P[:, :be.n_dof_owned].tocsr()          # per-rank block (block-Jacobi across GPUs)
-            self.hierarchy = amg.build_hierarchy(P, theta=self.amg_theta, coarse_size=self.amg_coarse_size)
-            amg.upload(be.lib, be.ctx, be.check, self.hierarchy, self.amg_pre, self.amg_post, self.amg_cheby_degree)
+            if self._pc_kind == _lib.PC_AMG:
+                self.hierarchy = amg.build_hierarchy(P, theta=self.amg_theta, coarse_size=self.amg_coarse_size)
+                amg.upload(be.lib, be.ctx, be.check, self.hierarchy, self.amg_pre, self.amg_post, self.amg_cheby_degree, index=0)
+                be.check(be.lib.knp_amg_use_native_level0(be.ctx, 0, 1))   # level 0 is the library's own P
+                self.hierarchies = [self.hierarchy]
+            else:
+                hk = amg.build_hierarchy(amg.restrict_to_fields(P, (0, 1, 2)), theta=self.amg_theta, coarse_size=self.amg_coarse_size)
+                hp = amg.build_hierarchy(amg.restrict_to_fields(P, (3,)), theta=self.amg_theta, coarse_size=self.amg_coarse_size)
+                amg.upload(be.lib, be.ctx, be.check, hk, self.amg_pre, self.amg_post, self.amg_cheby_degree, index=0)
+                amg.upload(be.lib, be.ctx, be.check, hp, self.amg_pre, self.amg_post, self.amg_cheby_degree, index=1)
+                be.check(be.lib.knp_amg_use_native_level0(be.ctx, 0, 2))   # ion fields of P
+                be.check(be.lib.knp_amg_use_native_level0(be.ctx, 1, 3))   # potential field of P
+                self.hierarchies = [hk, hp]
+                self.hierarchy = hk
             self.amg_setup_time = time.perf_counter() - tic
-            self.print(f"AMG hierarchy: {self.hierarchy.describe()} (host setup {self.amg_setup_time:0.3f} s)")
+            self.print(f"AMG hierarchies: {[h.describe() for h in self.hierarchies]} (host setup {self.amg_setup_time:0.3f} s)")
         self.P_ = "device CSR (see Backend.precond_csr)"
 
     def reassemble_preconditioner(self):
@@ -164,7 +180,7 @@ class SolverKNPEMI:
             self._rtol = 1e-13
         else:
             self.print("Setting up iterative solver ...")
-            self._pc_kind = {"hypre": _lib.PC_AMG, "amg": _lib.PC_AMG, "bjacobi": _lib.PC_VBJACOBI,
+            self._pc_kind = {"hypre": _lib.PC_AMG, "amg": _lib.PC_AMG, "btcc": _lib.PC_AMG_BT, "bjacobi": _lib.PC_VBJACOBI,
                              "vbjacobi": _lib.PC_VBJACOBI, "none": _lib.PC_NONE}[self.pc_type]
             self._rtol = self.ksp_rtol
         # initial conditions as initial guess (reference :177-209)
@@ -218,7 +234,7 @@ class SolverKNPEMI:
         be = self.backend
         self._sync()
         setup_timer += self.comm.allreduce_max(time.perf_counter() - tic)
-        if self.use_P_mat and self._pc_kind == _lib.PC_AMG:
+        if self.use_P_mat and self._pc_kind in (_lib.PC_AMG, _lib.PC_AMG_BT):
             tic = time.perf_counter()
             p.setup_preconditioner(self.use_block_Jacobi)
             self.assemble_preconditioner()
@@ -246,7 +262,7 @@ class SolverKNPEMI:
 
             tic = time.perf_counter()
             self.assemble()
-            if i > 1 and self.reassemble_P and (i % self.reassemble_N == 0) and self.use_P_mat and self._pc_kind == _lib.PC_AMG:
+            if i > 1 and self.reassemble_P and (i % self.reassemble_N == 0) and self.use_P_mat and self._pc_kind in (_lib.PC_AMG, _lib.PC_AMG_BT):
                 self.reassemble_preconditioner()
             self._sync()
             max_assembly_time = self.comm.allreduce_max(time.perf_counter() - tic)

@@ -70,6 +70,15 @@ struct KnpAmgLevel {
     int A_lanes = 8, P_lanes = 4, R_lanes = 8;
 };
 
+#define KNP_MAX_HIER 2
+struct KnpAmgHier {
+    int levels = 0, pre = 1, post = 1, cheby = 2;
+    int native0 = 0;   // level 0 runs on the pair-major P with node kernels: 0 no, 1 all fields, 2 ions only, 3 potential only
+    KnpAmgLevel lv[KNP_MAX_AMG_LEVELS];
+    int nc = 0;
+    double* cinv = nullptr;
+};
+
 struct knp_ctx {
     std::string err;
     hipStream_t stream = nullptr;
@@ -106,7 +115,7 @@ struct knp_ctx {
     double* d_vals = nullptr;
     int32_t *d_p_rowptr = nullptr, *d_p_colind = nullptr;
     double* d_p_vals = nullptr;
-    bool have_A = false, have_P = false;
+    bool have_A = false, have_P = false, have_cc = false;
     // work arrays
     double* d_cbar = nullptr;   // [3*n_c]
     double* d_fmat = nullptr;   // [6*npk*n_g]
@@ -125,12 +134,13 @@ struct knp_ctx {
     // preconditioner
     int pc_kind = KNP_PC_NONE;
     double* d_vbj = nullptr;  // [n_nodes_owned*16] compact vertex blocks
-    int amg_levels = 0, amg_pre = 1, amg_post = 1, amg_cheby = 2;
-    KnpAmgLevel amg[KNP_MAX_AMG_LEVELS];
-    int amg_nc = 0;
-    double* d_amg_cinv = nullptr;
+    KnpAmgHier hier[KNP_MAX_HIER];   // 0: all fields (block-Jacobi form) or ion fields; 1: potential
+    double* d_ML = nullptr;          // [n_nodes_owned] lumped mass of each node
+    double* d_cc = nullptr;          // [n_nodes_owned] diagonal Schur term psi / (sum_j z_j^2 k_j) / ML
+    double *d_t2 = nullptr, *d_w2 = nullptr;  // work vectors of the block-triangular preconditioner
     // null space
     int ns_on = 0;
+    int spmv_group = 8;   // lanes per node of the node-structured SpMV (0 = generic CSR kernel)
     // GMRES workspace
     int gm_restart = 0;
     double* d_V = nullptr;       // [(restart+1)*n_dof_local]

@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -144,15 +145,16 @@ k_assemble_pairs(int64_t n_pairs, int n_c, DevParams P, const int32_t* __restric
         }
         vals[rphi + 4 * q + 3] = phiphi;
     } else {
-        const int64_t base = (int64_t)4 * p0;
+        // P is stored pair-major: the 4 per-field entries of a node pair are contiguous (32 B)
+        (void)deg;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const double D = side ? P.De[j] : P.Di[j];
             const double z = P.z[j];
-            vals[base + (int64_t)j * deg + q] = M + P.dt * D * K;
+            vals[(int64_t)4 * p + j] = M + P.dt * D * K;
             phiphi += P.dt * D * z * z / P.psi * S[j];
         }
-        vals[base + (int64_t)3 * deg + q] = phiphi;
+        vals[(int64_t)4 * p + 3] = phiphi;
     }
 }
 
@@ -416,8 +418,8 @@ k_gamma_pairs(int64_t n_gp, int n_g, int dim, DevParams P, const int32_t* __rest
         vals[re + 4 * qe + 3] += m0;
         vals[re + 4 * dege + r] = -m0;
     } else {
-        vals[(int64_t)4 * pi0 + (int64_t)3 * degi + qi] -= m0;   // KNPEMIx_problem.py:737
-        vals[(int64_t)4 * pe0 + (int64_t)3 * dege + qe] -= m0;   // KNPEMIx_problem.py:738
+        vals[(int64_t)4 * (pi0 + qi) + 3] -= m0;   // KNPEMIx_problem.py:737
+        vals[(int64_t)4 * (pe0 + qe) + 3] -= m0;   // KNPEMIx_problem.py:738
     }
 }
 
@@ -493,6 +495,228 @@ k_spmv(int n_rows, const int32_t* __restrict__ rp, const int32_t* __restrict__ c
         else if (MODE == 1) y[row] = b[row] - s;
         else y[row] += s;
     }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// K4n: node-structured SpMV on the system matrix.  Same CSR value array, but one G-lane group per NODE
+// (its 4 rows are one contiguous chunk) and the column indices of the volume part are reconstructed from the
+// node graph (4 B per node pair instead of 40 B of colind): 16-byte loads of the (kk,kphi) pairs, of the
+// 4 phi-row entries and of the neighbour's 4 unknowns.  Only the membrane cross columns read colind.
+// ------------------------------------------------------------------------------------------
+template <int G, int MODE>
+__global__ void __launch_bounds__(NT)
+k_spmv_node(int n_nodes, const int32_t* __restrict__ pair_ptr, const int32_t* __restrict__ pair_col,
+            const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind, const double* __restrict__ vals,
+            const double* __restrict__ x, const double* __restrict__ b, double* __restrict__ y) {
+    const int node = (blockIdx.x * NT + threadIdx.x) / G;
+    const int lane = threadIdx.x & (G - 1);
+    double y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
+    if (node < n_nodes) {
+        const int p0 = pair_ptr[node];
+        const int deg = pair_ptr[node + 1] - p0;
+        const int4 rr = *reinterpret_cast<const int4*>(rowptr + 4 * (size_t)node);
+        const int r0 = rr.x, r1 = rr.y, r2 = rr.z, r3 = rr.w;
+        const int xp = (r1 - r0) - 2 * deg;
+        for (int q = lane; q < deg; q += G) {
+            const int nb = pair_col[p0 + q];
+            const double2 xa = *reinterpret_cast<const double2*>(x + 4 * (size_t)nb);
+            const double2 xb = *reinterpret_cast<const double2*>(x + 4 * (size_t)nb + 2);
+            const double2 a0 = *reinterpret_cast<const double2*>(vals + r0 + 2 * q);
+            const double2 a1 = *reinterpret_cast<const double2*>(vals + r1 + 2 * q);
+            const double2 a2 = *reinterpret_cast<const double2*>(vals + r2 + 2 * q);
+            const double2 f0 = *reinterpret_cast<const double2*>(vals + r3 + 4 * q);
+            const double2 f1 = *reinterpret_cast<const double2*>(vals + r3 + 4 * q + 2);
+            y0 += a0.x * xa.x + a0.y * xb.y;
+            y1 += a1.x * xa.y + a1.y * xb.y;
+            y2 += a2.x * xb.x + a2.y * xb.y;
+            y3 += f0.x * xa.x + f0.y * xa.y + f1.x * xb.x + f1.y * xb.y;
+        }
+        for (int r = lane; r < xp; r += G) {
+            const double xv = x[colind[r0 + 2 * deg + r]];
+            y0 += vals[r0 + 2 * deg + r] * xv;
+            y1 += vals[r1 + 2 * deg + r] * xv;
+            y2 += vals[r2 + 2 * deg + r] * xv;
+            y3 += vals[r3 + 4 * deg + r] * xv;
+        }
+    }
+#pragma unroll
+    for (int o = G >> 1; o > 0; o >>= 1) {
+        y0 += __shfl_xor(y0, o, G);
+        y1 += __shfl_xor(y1, o, G);
+        y2 += __shfl_xor(y2, o, G);
+        y3 += __shfl_xor(y3, o, G);
+    }
+    if (lane == 0 && node < n_nodes) {
+        double2 o0, o1;
+        if (MODE) {
+            const double2 b0 = *reinterpret_cast<const double2*>(b + 4 * (size_t)node);
+            const double2 b1 = *reinterpret_cast<const double2*>(b + 4 * (size_t)node + 2);
+            o0 = make_double2(b0.x - y0, b0.y - y1);
+            o1 = make_double2(b1.x - y2, b1.y - y3);
+        } else {
+            o0 = make_double2(y0, y1);
+            o1 = make_double2(y2, y3);
+        }
+        *reinterpret_cast<double2*>(y + 4 * (size_t)node) = o0;
+        *reinterpret_cast<double2*>(y + 4 * (size_t)node + 2) = o1;
+    }
+}
+template <int MODE>
+static void launch_spmv_node(hipStream_t st, int G, int n_nodes, const int32_t* pp, const int32_t* pc, const int32_t* rp,
+                             const int32_t* ci, const double* v, const double* x, const double* b, double* y) {
+    if (n_nodes <= 0) return;
+    switch (G) {
+        case 4: hipLaunchKernelGGL((k_spmv_node<4, MODE>), dim3(nblocks((int64_t)n_nodes * 4)), dim3(NT), 0, st, n_nodes, pp, pc, rp, ci, v, x, b, y); break;
+        case 8: hipLaunchKernelGGL((k_spmv_node<8, MODE>), dim3(nblocks((int64_t)n_nodes * 8)), dim3(NT), 0, st, n_nodes, pp, pc, rp, ci, v, x, b, y); break;
+        case 16: hipLaunchKernelGGL((k_spmv_node<16, MODE>), dim3(nblocks((int64_t)n_nodes * 16)), dim3(NT), 0, st, n_nodes, pp, pc, rp, ci, v, x, b, y); break;
+        default: hipLaunchKernelGGL((k_spmv_node<32, MODE>), dim3(nblocks((int64_t)n_nodes * 32)), dim3(NT), 0, st, n_nodes, pp, pc, rp, ci, v, x, b, y); break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Level 0 of the AMG cycle works on P itself, which has the node-graph structure with 4 decoupled fields:
+// one G-lane group per node, 32-byte loads of the pair's 4 entries and of the neighbour's 4 unknowns.
+// Columns outside the owned block (ghost nodes) are skipped: the per-GPU block of P.
+//   MODE 0: Chebyshev step  d = c1*d + c2*Dinv*(b - P xin), xout = xin + d
+//   MODE 1: residual        xout = b - P xin
+// ------------------------------------------------------------------------------------------
+template <int G, int MODE, int FM>   // FM field mask: 0 all four fields, 1 ion fields only, 2 potential only
+__global__ void __launch_bounds__(NT)
+k_pnode(int n_nodes, const int32_t* __restrict__ pair_ptr, const int32_t* __restrict__ pair_col,
+        const double* __restrict__ pv, const double* __restrict__ dinv, const double* __restrict__ b,
+        const double* __restrict__ xin, double c1, double c2, double* __restrict__ d, double* __restrict__ xout) {
+    const int node = (blockIdx.x * NT + threadIdx.x) / G;
+    const int lane = threadIdx.x & (G - 1);
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (node < n_nodes) {
+        const int p0 = pair_ptr[node];
+        const int deg = pair_ptr[node + 1] - p0;
+        for (int q = lane; q < deg; q += G) {
+            const int nb = pair_col[p0 + q];
+            if (nb < n_nodes) {
+                const double2 xb = *reinterpret_cast<const double2*>(xin + 4 * (size_t)nb + 2);
+                const double2 c = *reinterpret_cast<const double2*>(pv + 4 * (size_t)(p0 + q) + 2);
+                if (FM != 2) {
+                    const double2 xa = *reinterpret_cast<const double2*>(xin + 4 * (size_t)nb);
+                    const double2 a = *reinterpret_cast<const double2*>(pv + 4 * (size_t)(p0 + q));
+                    s0 += a.x * xa.x;
+                    s1 += a.y * xa.y;
+                    s2 += c.x * xb.x;
+                }
+                if (FM != 1) s3 += c.y * xb.y;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = G >> 1; o > 0; o >>= 1) {
+        s0 += __shfl_xor(s0, o, G);
+        s1 += __shfl_xor(s1, o, G);
+        s2 += __shfl_xor(s2, o, G);
+        s3 += __shfl_xor(s3, o, G);
+    }
+    if (lane == 0 && node < n_nodes) {
+        const size_t r = 4 * (size_t)node;
+        const double2 b0 = *reinterpret_cast<const double2*>(b + r);
+        const double2 b1 = *reinterpret_cast<const double2*>(b + r + 2);
+        if (MODE == 1) {
+            *reinterpret_cast<double2*>(xout + r) = make_double2(b0.x - s0, b0.y - s1);
+            *reinterpret_cast<double2*>(xout + r + 2) = make_double2(b1.x - s2, b1.y - s3);
+        } else {
+            const double2 i0 = *reinterpret_cast<const double2*>(dinv + r);
+            const double2 i1 = *reinterpret_cast<const double2*>(dinv + r + 2);
+            const double2 x0 = *reinterpret_cast<const double2*>(xin + r);
+            const double2 x1 = *reinterpret_cast<const double2*>(xin + r + 2);
+            double2 d0 = make_double2(0.0, 0.0), d1 = make_double2(0.0, 0.0);
+            if (c1 != 0.0) {
+                d0 = *reinterpret_cast<const double2*>(d + r);
+                d1 = *reinterpret_cast<const double2*>(d + r + 2);
+            }
+            // masked-out fields keep d = 0 and x unchanged (their Dinv is 0 in a single-field-class hierarchy)
+            d0.x = (FM == 2) ? 0.0 : c1 * d0.x + c2 * i0.x * (b0.x - s0);
+            d0.y = (FM == 2) ? 0.0 : c1 * d0.y + c2 * i0.y * (b0.y - s1);
+            d1.x = (FM == 2) ? 0.0 : c1 * d1.x + c2 * i1.x * (b1.x - s2);
+            d1.y = (FM == 1) ? 0.0 : c1 * d1.y + c2 * i1.y * (b1.y - s3);
+            *reinterpret_cast<double2*>(d + r) = d0;
+            *reinterpret_cast<double2*>(d + r + 2) = d1;
+            *reinterpret_cast<double2*>(xout + r) = make_double2(x0.x + d0.x, x0.y + d0.y);
+            *reinterpret_cast<double2*>(xout + r + 2) = make_double2(x1.x + d1.x, x1.y + d1.y);
+        }
+    }
+}
+template <int MODE, int FM>
+static void launch_pnode_fm(hipStream_t st, int G, int n_nodes, const int32_t* pp, const int32_t* pc, const double* pv,
+                            const double* dinv, const double* b, const double* xin, double c1, double c2, double* d, double* xout) {
+    switch (G) {
+        case 4: hipLaunchKernelGGL((k_pnode<4, MODE, FM>), dim3(nblocks((int64_t)n_nodes * 4)), dim3(NT), 0, st, n_nodes, pp, pc, pv, dinv, b, xin, c1, c2, d, xout); break;
+        case 8: hipLaunchKernelGGL((k_pnode<8, MODE, FM>), dim3(nblocks((int64_t)n_nodes * 8)), dim3(NT), 0, st, n_nodes, pp, pc, pv, dinv, b, xin, c1, c2, d, xout); break;
+        case 16: hipLaunchKernelGGL((k_pnode<16, MODE, FM>), dim3(nblocks((int64_t)n_nodes * 16)), dim3(NT), 0, st, n_nodes, pp, pc, pv, dinv, b, xin, c1, c2, d, xout); break;
+        default: hipLaunchKernelGGL((k_pnode<32, MODE, FM>), dim3(nblocks((int64_t)n_nodes * 32)), dim3(NT), 0, st, n_nodes, pp, pc, pv, dinv, b, xin, c1, c2, d, xout); break;
+    }
+}
+template <int MODE>
+static void launch_pnode(hipStream_t st, int fm, int G, int n_nodes, const int32_t* pp, const int32_t* pc, const double* pv,
+                         const double* dinv, const double* b, const double* xin, double c1, double c2, double* d, double* xout) {
+    if (n_nodes <= 0) return;
+    if (fm == 1) launch_pnode_fm<MODE, 1>(st, G, n_nodes, pp, pc, pv, dinv, b, xin, c1, c2, d, xout);
+    else if (fm == 2) launch_pnode_fm<MODE, 2>(st, G, n_nodes, pp, pc, pv, dinv, b, xin, c1, c2, d, xout);
+    else launch_pnode_fm<MODE, 0>(st, G, n_nodes, pp, pc, pv, dinv, b, xin, c1, c2, d, xout);
+}
+
+// ------------------------------------------------------------------------------------------
+// Block-triangular preconditioner pieces (ion blocks first, then the potential with a Cahouet-Chabard
+// approximation of its Schur complement):
+//   k_phi_rhs:   t = r ; t_phi -= A_{phi,k} z_k          (the phi rows of A, node-structured)
+//   k_schur_fin: z_phi = w_phi + cc * t_phi
+//   k_schur_diag: cc = psi / (sum_j z_j^2 k_j) / M_lumped  at every owned node
+// ------------------------------------------------------------------------------------------
+template <int G>
+__global__ void __launch_bounds__(NT)
+k_phi_rhs(int n_nodes, double z0, double z1, double z2, const int32_t* __restrict__ pair_ptr,
+          const int32_t* __restrict__ pair_col, const double* __restrict__ pair_M, const double* __restrict__ r,
+          const double* __restrict__ z, double* __restrict__ t) {
+    // t_phi = r_phi - sum_j z_j r_kj + M (sum_j z_j z_kj): equals r_phi - A_{phi,k} z_k for exact ion solves since
+    // A_{phi,kj} = z_j (A_{kj,kj} - M) (KNPEMIx_problem.py:586-591,598,603,633-634), without the cancellation
+    // that would amplify the V-cycle's error by 1/(1 - rho) ~ 10^2.
+    const int node = (blockIdx.x * NT + threadIdx.x) / G;
+    const int lane = threadIdx.x & (G - 1);
+    double s = 0.0;
+    if (node < n_nodes) {
+        const int p0 = pair_ptr[node];
+        const int deg = pair_ptr[node + 1] - p0;
+        for (int q = lane; q < deg; q += G) {
+            const int nb = pair_col[p0 + q];
+            const double2 za = *reinterpret_cast<const double2*>(z + 4 * (size_t)nb);
+            const double zc = z[4 * (size_t)nb + 2];
+            s += pair_M[p0 + q] * (z0 * za.x + z1 * za.y + z2 * zc);
+        }
+    }
+#pragma unroll
+    for (int o = G >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, G);
+    if (lane == 0 && node < n_nodes) {
+        const size_t i = 4 * (size_t)node;
+        const double2 ra = *reinterpret_cast<const double2*>(r + i);
+        const double2 rb = *reinterpret_cast<const double2*>(r + i + 2);
+        *reinterpret_cast<double2*>(t + i) = make_double2(0.0, 0.0);
+        *reinterpret_cast<double2*>(t + i + 2) = make_double2(0.0, rb.y - (z0 * ra.x + z1 * ra.y + z2 * rb.x) + s);
+    }
+}
+__global__ void __launch_bounds__(NT) k_schur_fin(int n_nodes, const double* __restrict__ cc, const double* __restrict__ t,
+                                                  const double* __restrict__ w, double* __restrict__ z) {
+    const int n = blockIdx.x * NT + threadIdx.x;
+    if (n >= n_nodes) return;
+    z[(size_t)4 * n + 3] = w[(size_t)4 * n + 3] + cc[n] * t[(size_t)4 * n + 3];
+}
+__global__ void __launch_bounds__(NT)
+k_schur_diag(int n_nodes, double psi, double z0, double z1, double z2, const int32_t* __restrict__ node_vertex,
+             const uint8_t* __restrict__ node_side, FieldPtrs f, const double* __restrict__ ML, double* __restrict__ cc) {
+    const int n = blockIdx.x * NT + threadIdx.x;
+    if (n >= n_nodes) return;
+    const int v = node_vertex[n];
+    const int sd = node_side[n];
+    const double s = z0 * z0 * (sd ? f.ke[0] : f.ki[0])[v] + z1 * z1 * (sd ? f.ke[1] : f.ki[1])[v] +
+                     z2 * z2 * (sd ? f.ke[2] : f.ki[2])[v];
+    cc[n] = psi / (s * ML[n]);
 }
 
 template <int MODE, int TAG = 0>
@@ -1071,23 +1295,17 @@ int knp_create(knp_ctx** out, const knp_mesh_desc* mesh) {
     KCHK(dev_upload(ctx, &ctx->d_colind, g.colind));
     HIPCHK(hipMalloc((void**)&ctx->d_vals, std::max<int64_t>(ctx->nnz, 1) * sizeof(double)));
     HIPCHK(hipMemset(ctx->d_vals, 0, std::max<int64_t>(ctx->nnz, 1) * sizeof(double)));
-    // P pattern: row (n,f) -> cols (nb,f)
-    {
-        const int no = g.n_nodes_owned;
-        std::vector<int32_t> prp((size_t)4 * no + 1), pci((size_t)4 * ctx->n_pairs);
-        for (int n = 0; n < no; ++n) {
-            const int p0 = g.pair_ptr[n], deg = g.pair_ptr[n + 1] - p0;
-            for (int f = 0; f < 4; ++f) {
-                prp[(size_t)4 * n + f] = 4 * p0 + f * deg;
-                for (int q = 0; q < deg; ++q) pci[(size_t)4 * p0 + (size_t)f * deg + q] = 4 * g.pair_col[p0 + q] + f;
-            }
-        }
-        prp[(size_t)4 * no] = (int32_t)(4 * ctx->n_pairs);
-        KCHK(dev_upload(ctx, &ctx->d_p_rowptr, prp));
-        KCHK(dev_upload(ctx, &ctx->d_p_colind, pci));
-        HIPCHK(hipMalloc((void**)&ctx->d_p_vals, std::max<int64_t>(4 * ctx->n_pairs, 1) * sizeof(double)));
-        HIPCHK(hipMemset(ctx->d_p_vals, 0, std::max<int64_t>(4 * ctx->n_pairs, 1) * sizeof(double)));
+    {   // lumped mass per owned node (row sums of the P1 mass matrix): diagonal Schur term of the potential
+        std::vector<double> ML(std::max(g.n_nodes_owned, 1), 0.0);
+        for (int n = 0; n < g.n_nodes_owned; ++n)
+            for (int pq = g.pair_ptr[n]; pq < g.pair_ptr[n + 1]; ++pq) ML[n] += g.pair_M[pq];
+        KCHK(dev_upload(ctx, &ctx->d_ML, ML));
+        HIPCHK(hipMalloc((void**)&ctx->d_cc, std::max<size_t>(g.n_nodes_owned, 1) * sizeof(double)));
+        HIPCHK(hipMemset(ctx->d_cc, 0, std::max<size_t>(g.n_nodes_owned, 1) * sizeof(double)));
     }
+    // P (block-Jacobi form) is stored pair-major on the device: p_vals[4*pair + field]
+    HIPCHK(hipMalloc((void**)&ctx->d_p_vals, std::max<int64_t>(4 * ctx->n_pairs, 1) * sizeof(double)));
+    HIPCHK(hipMemset(ctx->d_p_vals, 0, std::max<int64_t>(4 * ctx->n_pairs, 1) * sizeof(double)));
     const int npk = dim * (dim + 1) / 2;
     HIPCHK(hipMalloc((void**)&ctx->d_cbar, (size_t)3 * g.n_c * sizeof(double)));
     HIPCHK(hipMalloc((void**)&ctx->d_fmat, std::max<size_t>((size_t)6 * npk * g.n_g, 1) * sizeof(double)));
@@ -1101,6 +1319,13 @@ int knp_create(knp_ctx** out, const knp_mesh_desc* mesh) {
     HIPCHK(hipMalloc((void**)&ctx->d_y, RED_SLOTS * sizeof(double)));
     HIPCHK(hipMalloc((void**)&ctx->d_vbj, std::max<size_t>((size_t)16 * g.n_nodes_owned, 1) * sizeof(double)));
     ctx->n_red_blocks = std::min(RED_BLOCKS, nblocks(ctx->n_dof_owned));
+    {
+        const double avg_deg = g.n_nodes_owned ? (double)ctx->n_pairs / g.n_nodes_owned : 1.0;
+        ctx->spmv_group = avg_deg <= 4.5 ? 4 : avg_deg <= 9.0 ? 8 : avg_deg <= 20.0 ? 16 : 32;
+        const char* e = getenv("KNP_SPMV");
+        if (e && !strcmp(e, "csr")) ctx->spmv_group = 0;   // generic CSR kernel (k_spmv<L,*,1>)
+        else if (e && atoi(e) > 0) ctx->spmv_group = atoi(e);
+    }
     // free the big host arrays that are no longer needed (pattern kept for export)
     std::vector<int32_t>().swap(g.contrib_cell);
     std::vector<double>().swap(g.contrib_k);
@@ -1128,13 +1353,17 @@ int knp_destroy(knp_ctx* ctx) {
     dev_free(ctx->d_V); dev_free(ctx->d_w); dev_free(ctx->d_t);
     for (auto& p : ctx->progs) { dev_free(p.d_code); dev_free(p.d_consts); }
     dev_free(ctx->d_prog_code); dev_free(ctx->d_prog_consts); dev_free(ctx->d_prog_len);
-    for (int l = 0; l < KNP_MAX_AMG_LEVELS; ++l) {
-        KnpAmgLevel& L = ctx->amg[l];
-        dev_free(L.A_rp); dev_free(L.A_ci); dev_free(L.A_v); dev_free(L.inv_diag);
-        dev_free(L.P_rp); dev_free(L.P_ci); dev_free(L.P_v); dev_free(L.R_rp); dev_free(L.R_ci); dev_free(L.R_v);
-        dev_free(L.x); dev_free(L.b); dev_free(L.r); dev_free(L.d); dev_free(L.r2);
+    for (int h = 0; h < KNP_MAX_HIER; ++h) {
+        KnpAmgHier& H = ctx->hier[h];
+        for (int l = 0; l < KNP_MAX_AMG_LEVELS; ++l) {
+            KnpAmgLevel& L = H.lv[l];
+            dev_free(L.A_rp); dev_free(L.A_ci); dev_free(L.A_v); dev_free(L.inv_diag);
+            dev_free(L.P_rp); dev_free(L.P_ci); dev_free(L.P_v); dev_free(L.R_rp); dev_free(L.R_ci); dev_free(L.R_v);
+            dev_free(L.x); dev_free(L.b); dev_free(L.r); dev_free(L.d); dev_free(L.r2);
+        }
+        dev_free(H.cinv);
     }
-    dev_free(ctx->d_amg_cinv);
+    dev_free(ctx->d_ML); dev_free(ctx->d_cc); dev_free(ctx->d_t2); dev_free(ctx->d_w2);
     dev_free(ctx->d_defl_mode); dev_free(ctx->d_defl_einv);
     delete ctx;
     return KNP_OK;
@@ -1191,9 +1420,20 @@ int knp_get_precond_csr(const knp_ctx* cctx, int32_t* rp, int32_t* ci, double* v
     knp_ctx* ctx = const_cast<knp_ctx*>(cctx);
     if (!ctx || !rp || !ci || !vals) return KNP_E_ARG;
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    HIPCHK(hipMemcpy(rp, ctx->d_p_rowptr, ((size_t)ctx->n_dof_owned + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(ci, ctx->d_p_colind, (size_t)4 * ctx->n_pairs * sizeof(int32_t), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(vals, ctx->d_p_vals, (size_t)4 * ctx->n_pairs * sizeof(double), hipMemcpyDeviceToHost));
+    std::vector<double> pm((size_t)4 * ctx->n_pairs);
+    HIPCHK(hipMemcpy(pm.data(), ctx->d_p_vals, pm.size() * sizeof(double), hipMemcpyDeviceToHost));
+    const KnpHostGraph& g = ctx->g;
+    for (int n = 0; n < g.n_nodes_owned; ++n) {
+        const int p0 = g.pair_ptr[n], deg = g.pair_ptr[n + 1] - p0;
+        for (int f = 0; f < 4; ++f) {
+            rp[(size_t)4 * n + f] = 4 * p0 + f * deg;
+            for (int q = 0; q < deg; ++q) {
+                ci[(size_t)4 * p0 + (size_t)f * deg + q] = 4 * g.pair_col[p0 + q] + f;
+                vals[(size_t)4 * p0 + (size_t)f * deg + q] = pm[(size_t)4 * (p0 + q) + f];
+            }
+        }
+    }
+    rp[(size_t)4 * g.n_nodes_owned] = (int32_t)(4 * ctx->n_pairs);
     return KNP_OK;
 }
 int knp_get_device_csr(const knp_ctx* ctx, const int32_t** rp, const int32_t** ci, const double** v) {
@@ -1325,6 +1565,9 @@ int knp_assemble_matrix(knp_ctx* ctx, const knp_fields* fields) {
                                ctx->d_gcptr, ctx->d_gc_facet, ctx->d_gc_lab, ctx->d_fmeas, ctx->d_fmat, ctx->d_pair_ptr,
                                ctx->d_rowptr, ctx->d_vals);
     }
+    hipLaunchKernelGGL(k_schur_diag, dim3(nblocks(g.n_nodes_owned)), dim3(NT), 0, ctx->stream, g.n_nodes_owned, ctx->psi, ctx->z[0], ctx->z[1],
+                       ctx->z[2], ctx->d_node_vertex, ctx->d_node_side, f, ctx->d_ML, ctx->d_cc);
+    ctx->have_cc = true;
     HIPCHK(hipGetLastError());
     ctx->have_A = true;
     if (ctx->pc_kind == KNP_PC_VBJACOBI) {
@@ -1492,6 +1735,17 @@ static int ensure_work(knp_ctx* ctx, int restart) {
 static int spmv_A(knp_ctx* ctx, double* x, const double* b, double* y, bool residual) {
     KCHK(halo_update(ctx, x));
     ProfScope ps(ctx, 0);
+    if (ctx->spmv_group > 0) {
+        const KnpHostGraph& g = ctx->g;
+        if (residual)
+            launch_spmv_node<1>(ctx->stream, ctx->spmv_group, g.n_nodes_owned, ctx->d_pair_ptr, ctx->d_pair_col, ctx->d_rowptr,
+                                ctx->d_colind, ctx->d_vals, x, b, y);
+        else
+            launch_spmv_node<0>(ctx->stream, ctx->spmv_group, g.n_nodes_owned, ctx->d_pair_ptr, ctx->d_pair_col, ctx->d_rowptr,
+                                ctx->d_colind, ctx->d_vals, x, b, y);
+        HIPCHK(hipGetLastError());
+        return KNP_OK;
+    }
     const int lanes = pick_lanes(ctx->n_dof_owned ? (double)ctx->nnz / ctx->n_dof_owned : 1.0);
     if (residual)
         launch_spmv<1, 1>(ctx->stream, lanes, ctx->n_dof_owned, ctx->d_rowptr, ctx->d_colind, ctx->d_vals, x, b, y);
@@ -1526,31 +1780,37 @@ int knp_nullspace_test(knp_ctx* ctx, double* out_norm) {
 }
 
 // ---- AMG ---------------------------------------------------------------------------------
-int knp_amg_reset(knp_ctx* ctx, int32_t n_levels, int32_t pre, int32_t post, int32_t cheby) {
-    CHECK_CTX(ctx);
-    if (n_levels < 1 || n_levels > KNP_MAX_AMG_LEVELS || pre < 0 || post < 0 || cheby < 1) { ctx->err = "bad AMG parameters"; return KNP_E_ARG; }
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+static void free_hier(KnpAmgHier& H) {
     for (int l = 0; l < KNP_MAX_AMG_LEVELS; ++l) {
-        KnpAmgLevel& L = ctx->amg[l];
+        KnpAmgLevel& L = H.lv[l];
         dev_free(L.A_rp); dev_free(L.A_ci); dev_free(L.A_v); dev_free(L.inv_diag);
         dev_free(L.P_rp); dev_free(L.P_ci); dev_free(L.P_v); dev_free(L.R_rp); dev_free(L.R_ci); dev_free(L.R_v);
         dev_free(L.x); dev_free(L.b); dev_free(L.r); dev_free(L.d); dev_free(L.r2);
         L.n = L.n_coarse = 0;
     }
-    dev_free(ctx->d_amg_cinv);
-    ctx->amg_nc = 0;
-    ctx->amg_levels = n_levels; ctx->amg_pre = pre; ctx->amg_post = post; ctx->amg_cheby = cheby;
+    dev_free(H.cinv);
+    H.nc = 0; H.levels = 0; H.native0 = 0;
+}
+int knp_amg_reset(knp_ctx* ctx, int32_t hier, int32_t n_levels, int32_t pre, int32_t post, int32_t cheby) {
+    CHECK_CTX(ctx);
+    if (hier < 0 || hier >= KNP_MAX_HIER || n_levels < 1 || n_levels > KNP_MAX_AMG_LEVELS || pre < 0 || post < 0 || cheby < 1) { ctx->err = "bad AMG parameters"; return KNP_E_ARG; }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    KnpAmgHier& H = ctx->hier[hier];
+    free_hier(H);
+    H.levels = n_levels; H.pre = pre; H.post = post; H.cheby = cheby;
     return KNP_OK;
 }
-int knp_amg_set_level(knp_ctx* ctx, int32_t level, int32_t n_rows, int32_t n_cols_halo, const int32_t* A_rp,
+int knp_amg_set_level(knp_ctx* ctx, int32_t hier, int32_t level, int32_t n_rows, int32_t n_cols_halo, const int32_t* A_rp,
                       const int32_t* A_ci, const double* A_v, const double* inv_diag, double lambda_max, int32_t n_coarse,
                       const int32_t* P_rp, const int32_t* P_ci, const double* P_v, const int32_t* R_rp, const int32_t* R_ci,
                       const double* R_v) {
     CHECK_CTX(ctx);
     (void)n_cols_halo;
-    if (level < 0 || level >= ctx->amg_levels || n_rows <= 0 || !A_rp || !A_ci || !A_v || !inv_diag) { ctx->err = "bad AMG level arguments"; return KNP_E_ARG; }
+    if (hier < 0 || hier >= KNP_MAX_HIER) { ctx->err = "bad hierarchy index"; return KNP_E_ARG; }
+    KnpAmgHier& H = ctx->hier[hier];
+    if (level < 0 || level >= H.levels || n_rows <= 0 || !A_rp || !A_ci || !A_v || !inv_diag) { ctx->err = "bad AMG level arguments"; return KNP_E_ARG; }
     if (level == 0 && n_rows != ctx->n_dof_owned) { ctx->err = "AMG level 0 must have n_dof_owned rows"; return KNP_E_ARG; }
-    KnpAmgLevel& L = ctx->amg[level];
+    KnpAmgLevel& L = H.lv[level];
     const int64_t nnzA = A_rp[n_rows];
     for (int64_t k = 0; k < nnzA; ++k)
         if (A_ci[k] < 0 || A_ci[k] >= n_rows) { ctx->err = "AMG level matrix column out of range"; return KNP_E_ARG; }
@@ -1586,96 +1846,133 @@ int knp_amg_set_level(knp_ctx* ctx, int32_t level, int32_t n_rows, int32_t n_col
     HIPCHK(hipMemset(L.d, 0, (size_t)n_rows * sizeof(double)));
     return KNP_OK;
 }
-int knp_amg_set_coarse(knp_ctx* ctx, int32_t n, const double* inv) {
+int knp_amg_use_native_level0(knp_ctx* ctx, int32_t hier, int32_t mode) {
     CHECK_CTX(ctx);
-    if (n <= 0 || !inv) return KNP_E_ARG;
-    dev_free(ctx->d_amg_cinv);
-    KCHK(dev_upload_raw(ctx, &ctx->d_amg_cinv, inv, (size_t)n * n));
-    ctx->amg_nc = n;
+    if (hier < 0 || hier >= KNP_MAX_HIER || mode < 0 || mode > 3) { ctx->err = "bad arguments"; return KNP_E_ARG; }
+    if (mode && !ctx->have_P) { ctx->err = "P not assembled"; return KNP_E_STATE; }
+    ctx->hier[hier].native0 = mode;
+    return KNP_OK;
+}
+int knp_amg_set_coarse(knp_ctx* ctx, int32_t hier, int32_t n, const double* inv) {
+    CHECK_CTX(ctx);
+    if (hier < 0 || hier >= KNP_MAX_HIER || n <= 0 || !inv) return KNP_E_ARG;
+    KnpAmgHier& H = ctx->hier[hier];
+    dev_free(H.cinv);
+    KCHK(dev_upload_raw(ctx, &H.cinv, inv, (size_t)n * n));
+    H.nc = n;
     return KNP_OK;
 }
 
 // Chebyshev smoothing sweep of A x = b on one level with ping-pong buffers.  On entry the iterate is in
 // *cur (ignored when zero_guess); the sweep alternates between bufA and bufB and leaves *cur pointing at
 // the buffer that holds the result.
-static void amg_smooth(knp_ctx* ctx, KnpAmgLevel& L, const double* b, double** cur, double* bufA, double* bufB, bool zero_guess) {
+static void amg_smooth(knp_ctx* ctx, KnpAmgHier& H, int l, const double* b, double** cur, double* bufA, double* bufB, bool zero_guess) {
+    KnpAmgLevel& L = H.lv[l];
     const double lmax = 1.1 * L.lambda_max, lmin = 0.1 * L.lambda_max;  // smoothing interval [0.1, 1.1] * lambda_max
     const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
     const double sigma = theta / delta;
     double rho_old = 1.0 / sigma;
-    const int deg = ctx->amg_cheby;
+    const int deg = H.cheby;
     hipStream_t st = ctx->stream;
     auto other = [&](double* p) { return p == bufA ? bufB : bufA; };
+    const bool native0 = (l == 0) && H.native0 > 0;
+    auto step = [&](const double* xin, double c1, double c2, double* out) {
+        if (native0)
+            launch_pnode<0>(st, H.native0 - 1, ctx->spmv_group > 0 ? ctx->spmv_group : 8, ctx->g.n_nodes_owned, ctx->d_pair_ptr,
+                            ctx->d_pair_col, ctx->d_p_vals, L.inv_diag, b, xin, c1, c2, L.d, out);
+        else
+            launch_cheby(st, L.A_lanes, L.n, L.A_rp, L.A_ci, L.A_v, L.inv_diag, b, xin, c1, c2, L.d, out);
+    };
     if (zero_guess) {
         hipLaunchKernelGGL(k_cheby_first, dim3(std::min(nblocks(L.n), 2048)), dim3(NT), 0, st, L.n, 1.0 / theta, L.inv_diag, b, L.d, *cur);
     } else {
         double* out = other(*cur);
-        launch_cheby(st, L.A_lanes, L.n, L.A_rp, L.A_ci, L.A_v, L.inv_diag, b, *cur, 0.0, 1.0 / theta, L.d, out);
+        step(*cur, 0.0, 1.0 / theta, out);
         *cur = out;
     }
     for (int k = 1; k < deg; ++k) {
         const double rho = 1.0 / (2.0 * sigma - rho_old);
         double* out = other(*cur);
-        launch_cheby(st, L.A_lanes, L.n, L.A_rp, L.A_ci, L.A_v, L.inv_diag, b, *cur, rho * rho_old, 2.0 * rho / delta, L.d, out);
+        step(*cur, rho * rho_old, 2.0 * rho / delta, out);
         *cur = out;
         rho_old = rho;
     }
 }
 
 // number of buffer flips one level performs (decides where to start so that the result lands in `want`)
-static int amg_flips(const knp_ctx* ctx, bool last_no_dense) {
-    const int deg = ctx->amg_cheby;
-    int sweeps = last_no_dense ? (ctx->amg_pre + ctx->amg_post) : 0;
-    if (last_no_dense) return sweeps > 0 ? (deg - 1) + (sweeps - 1) * deg : 0;
+static int amg_flips(const KnpAmgHier& H, bool last_no_dense) {
+    const int deg = H.cheby;
+    if (last_no_dense) {
+        const int sweeps = H.pre + H.post;
+        return sweeps > 0 ? (deg - 1) + (sweeps - 1) * deg : 0;
+    }
     int f = 0;
-    if (ctx->amg_pre > 0) f += (deg - 1) + (ctx->amg_pre - 1) * deg;
-    f += ctx->amg_post * deg;
+    if (H.pre > 0) f += (deg - 1) + (H.pre - 1) * deg;
+    f += H.post * deg;
     return f;
 }
 
 // V-cycle on level l for right-hand side b.  The result is written to `want` when non-null (level 0: the
 // caller's z), otherwise to whichever of the level's two buffers the ping-pong ends in; returns that pointer.
-static double* amg_vcycle(knp_ctx* ctx, int l, const double* b, double* want) {
+static double* amg_vcycle(knp_ctx* ctx, KnpAmgHier& H, int l, const double* b, double* want) {
     hipStream_t st = ctx->stream;
-    KnpAmgLevel& L = ctx->amg[l];
-    const bool last = (l == ctx->amg_levels - 1);
+    KnpAmgLevel& L = H.lv[l];
+    const bool last = (l == H.levels - 1);
     double* bufA = want ? want : L.x;
     double* bufB = L.r2;
-    if (last && ctx->amg_nc > 0) {
-        hipLaunchKernelGGL(k_dense_matvec, dim3(nblocks((int64_t)ctx->amg_nc * 64)), dim3(NT), 0, st, ctx->amg_nc, ctx->d_amg_cinv, b, bufA);
+    if (last && H.nc > 0) {
+        hipLaunchKernelGGL(k_dense_matvec, dim3(nblocks((int64_t)H.nc * 64)), dim3(NT), 0, st, H.nc, H.cinv, b, bufA);
         return bufA;
     }
-    const int flips = amg_flips(ctx, last);
+    const int flips = amg_flips(H, last);
     double* cur = (flips & 1) ? bufB : bufA;    // start so that the final iterate lands in bufA
     if (last) {  // no coarse inverse supplied: smooth only
         bool zero = true;
-        for (int sw = 0; sw < ctx->amg_pre + ctx->amg_post; ++sw) { amg_smooth(ctx, L, b, &cur, bufA, bufB, zero); zero = false; }
+        for (int sw = 0; sw < H.pre + H.post; ++sw) { amg_smooth(ctx, H, l, b, &cur, bufA, bufB, zero); zero = false; }
         if (zero) { hipLaunchKernelGGL(k_fill, dim3(std::min(nblocks(L.n), 2048)), dim3(NT), 0, st, L.n, 0.0, bufA); cur = bufA; }
         return cur;
     }
-    KnpAmgLevel& C = ctx->amg[l + 1];
+    KnpAmgLevel& C = H.lv[l + 1];
     const int nc = L.n_coarse;
     bool zero = true;
-    for (int sw = 0; sw < ctx->amg_pre; ++sw) { amg_smooth(ctx, L, b, &cur, bufA, bufB, zero); zero = false; }
+    for (int sw = 0; sw < H.pre; ++sw) { amg_smooth(ctx, H, l, b, &cur, bufA, bufB, zero); zero = false; }
     if (zero) hipLaunchKernelGGL(k_fill, dim3(std::min(nblocks(L.n), 2048)), dim3(NT), 0, st, L.n, 0.0, cur);
     // r = b - A x ; b_c = R r
-    launch_spmv<1>(st, L.A_lanes, L.n, L.A_rp, L.A_ci, L.A_v, cur, b, L.r);
+    if (l == 0 && H.native0 > 0)
+        launch_pnode<1>(st, H.native0 - 1, ctx->spmv_group > 0 ? ctx->spmv_group : 8, ctx->g.n_nodes_owned, ctx->d_pair_ptr,
+                        ctx->d_pair_col, ctx->d_p_vals, L.inv_diag, b, cur, 0.0, 0.0, L.d, L.r);
+    else
+        launch_spmv<1>(st, L.A_lanes, L.n, L.A_rp, L.A_ci, L.A_v, cur, b, L.r);
     launch_spmv<0>(st, L.R_lanes, nc, L.R_rp, L.R_ci, L.R_v, L.r, nullptr, C.b);
-    double* xc = amg_vcycle(ctx, l + 1, C.b, nullptr);
+    double* xc = amg_vcycle(ctx, H, l + 1, C.b, nullptr);
     // x += P x_c (fused)
     launch_spmv<2>(st, L.P_lanes, L.n, L.P_rp, L.P_ci, L.P_v, xc, nullptr, cur);
-    for (int sw = 0; sw < ctx->amg_post; ++sw) amg_smooth(ctx, L, b, &cur, bufA, bufB, false);
+    for (int sw = 0; sw < H.post; ++sw) amg_smooth(ctx, H, l, b, &cur, bufA, bufB, false);
     return cur;
+}
+
+static int check_hier(knp_ctx* ctx, int h) {
+    KnpAmgHier& H = ctx->hier[h];
+    if (H.levels < 1 || H.lv[0].n != ctx->n_dof_owned) { ctx->err = "AMG hierarchy " + std::to_string(h) + " not supplied"; return KNP_E_STATE; }
+    for (int l = 0; l < H.levels - 1; ++l)
+        if (H.lv[l].n_coarse != H.lv[l + 1].n) { ctx->err = "AMG level sizes inconsistent"; return KNP_E_STATE; }
+    if (H.nc > 0 && H.nc != H.lv[H.levels - 1].n) { ctx->err = "AMG coarse inverse size mismatch"; return KNP_E_STATE; }
+    return KNP_OK;
 }
 
 int knp_pc_setup(knp_ctx* ctx, int32_t kind) {
     CHECK_CTX(ctx);
-    if (kind != KNP_PC_NONE && kind != KNP_PC_VBJACOBI && kind != KNP_PC_AMG) { ctx->err = "unknown pc kind"; return KNP_E_ARG; }
-    if (kind == KNP_PC_AMG) {
-        if (ctx->amg_levels < 1 || ctx->amg[0].n != ctx->n_dof_owned) { ctx->err = "AMG hierarchy not supplied"; return KNP_E_STATE; }
-        for (int l = 0; l < ctx->amg_levels - 1; ++l)
-            if (ctx->amg[l].n_coarse != ctx->amg[l + 1].n) { ctx->err = "AMG level sizes inconsistent"; return KNP_E_STATE; }
-        if (ctx->amg_nc > 0 && ctx->amg_nc != ctx->amg[ctx->amg_levels - 1].n) { ctx->err = "AMG coarse inverse size mismatch"; return KNP_E_STATE; }
+    if (kind != KNP_PC_NONE && kind != KNP_PC_VBJACOBI && kind != KNP_PC_AMG && kind != KNP_PC_AMG_BT) { ctx->err = "unknown pc kind"; return KNP_E_ARG; }
+    if (kind == KNP_PC_AMG) KCHK(check_hier(ctx, 0));
+    if (kind == KNP_PC_AMG_BT) {
+        KCHK(check_hier(ctx, 0));
+        KCHK(check_hier(ctx, 1));
+        if (!ctx->d_t2) {
+            HIPCHK(hipMalloc((void**)&ctx->d_t2, std::max(ctx->n_dof_local, 1) * sizeof(double)));
+            HIPCHK(hipMalloc((void**)&ctx->d_w2, std::max(ctx->n_dof_local, 1) * sizeof(double)));
+            HIPCHK(hipMemset(ctx->d_t2, 0, std::max(ctx->n_dof_local, 1) * sizeof(double)));
+            HIPCHK(hipMemset(ctx->d_w2, 0, std::max(ctx->n_dof_local, 1) * sizeof(double)));
+        }
     }
     ctx->pc_kind = kind;
     if (kind == KNP_PC_VBJACOBI && ctx->have_A) {
@@ -1709,12 +2006,28 @@ static int pc_apply_proj(knp_ctx* ctx, const double* r, double* z, int64_t cnt) 
                 hipLaunchKernelGGL(k_vbj_apply, dim3(nblocks(g.n_nodes_owned)), dim3(NT), 0, ctx->stream, g.n_nodes_owned,
                                    ctx->d_node_side, ctx->d_node_gv, ctx->d_gv_node_e, ctx->d_vbj, r, z);
                 break;
-            case KNP_PC_AMG:
-                {
-                    double* out = amg_vcycle(ctx, 0, r, z);
-                    if (out != z) HIPCHK(hipMemcpyAsync(z, out, (size_t)ctx->n_dof_owned * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-                }
+            case KNP_PC_AMG: {
+                double* out = amg_vcycle(ctx, ctx->hier[0], 0, r, z);
+                if (out != z) HIPCHK(hipMemcpyAsync(z, out, (size_t)ctx->n_dof_owned * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
                 break;
+            }
+            case KNP_PC_AMG_BT: {
+                // z_k = V_k r_k ; t_phi = r_phi - A_{phi k} z_k ; z_phi = V_phi t_phi + cc * t_phi
+                if (!ctx->have_A || !ctx->have_cc) { ctx->err = "block-triangular preconditioner needs an assembled matrix"; return KNP_E_STATE; }
+                const int G = ctx->spmv_group > 0 ? ctx->spmv_group : 8;
+                double* out = amg_vcycle(ctx, ctx->hier[0], 0, r, z);
+                if (out != z) HIPCHK(hipMemcpyAsync(z, out, (size_t)ctx->n_dof_owned * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+                KCHK(halo_update(ctx, z));   // the mass-matrix row may reach ghost ion unknowns
+                switch (G) {
+                    case 4: hipLaunchKernelGGL((k_phi_rhs<4>), dim3(nblocks((int64_t)g.n_nodes_owned * 4)), dim3(NT), 0, ctx->stream, g.n_nodes_owned, ctx->z[0], ctx->z[1], ctx->z[2], ctx->d_pair_ptr, ctx->d_pair_col, ctx->d_pair_M, r, z, ctx->d_t2); break;
+                    case 8: hipLaunchKernelGGL((k_phi_rhs<8>), dim3(nblocks((int64_t)g.n_nodes_owned * 8)), dim3(NT), 0, ctx->stream, g.n_nodes_owned, ctx->z[0], ctx->z[1], ctx->z[2], ctx->d_pair_ptr, ctx->d_pair_col, ctx->d_pair_M, r, z, ctx->d_t2); break;
+                    case 16: hipLaunchKernelGGL((k_phi_rhs<16>), dim3(nblocks((int64_t)g.n_nodes_owned * 16)), dim3(NT), 0, ctx->stream, g.n_nodes_owned, ctx->z[0], ctx->z[1], ctx->z[2], ctx->d_pair_ptr, ctx->d_pair_col, ctx->d_pair_M, r, z, ctx->d_t2); break;
+                    default: hipLaunchKernelGGL((k_phi_rhs<32>), dim3(nblocks((int64_t)g.n_nodes_owned * 32)), dim3(NT), 0, ctx->stream, g.n_nodes_owned, ctx->z[0], ctx->z[1], ctx->z[2], ctx->d_pair_ptr, ctx->d_pair_col, ctx->d_pair_M, r, z, ctx->d_t2); break;
+                }
+                double* w = amg_vcycle(ctx, ctx->hier[1], 0, ctx->d_t2, ctx->d_w2);
+                hipLaunchKernelGGL(k_schur_fin, dim3(nblocks(g.n_nodes_owned)), dim3(NT), 0, ctx->stream, g.n_nodes_owned, ctx->d_cc, ctx->d_t2, w, z);
+                break;
+            }
             default:
                 HIPCHK(hipMemcpyAsync(z, r, (size_t)ctx->n_dof_owned * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
                 break;

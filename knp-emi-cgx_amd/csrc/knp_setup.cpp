@@ -300,17 +300,20 @@ int knp_build_graph(const knp_mesh_desc* m, KnpHostGraph& g) {
     }
 
     // ---- 5. CSR pattern of A ----------------------------------------------------------------
-    // row (n,j<3): [ (nb,j),(nb,3) for nb in pairs ] ++ [ (cross,3) ]   length 2*deg + x
-    // row (n,3)  : [ (nb,0..3) for nb in pairs ]     ++ [ (cross,3) ]   length 4*deg + x
+    // row (n,j<3): [ (nb,j),(nb,3) for nb in pairs ] ++ [ (cross,3) ]   length 2*deg + xp
+    // row (n,3)  : [ (nb,0..3) for nb in pairs ]     ++ [ (cross,3) ]   length 4*deg + xp
+    // xp = number of cross columns rounded up to even (one explicit zero on the node's own potential
+    // column when odd): every row then starts at an even index, i.e. 16-byte aligned for vector loads.
     g.rowptr.assign((size_t)4 * no + 1, 0);
     int64_t nnz = 0;
     for (int n = 0; n < no; ++n) {
         int deg = g.pair_ptr[n + 1] - g.pair_ptr[n];
         int A = g.node_gv[n];
         int x = A >= 0 ? g.gptr[A + 1] - g.gptr[A] : 0;
+        int xp = (x + 1) & ~1;
         for (int f = 0; f < 4; ++f) {
             g.rowptr[(size_t)4 * n + f] = (int32_t)nnz;
-            nnz += (f < 3 ? 2 : 4) * (int64_t)deg + x;
+            nnz += (f < 3 ? 2 : 4) * (int64_t)deg + xp;
         }
     }
     if (nnz > 0x7fffffffLL) { g.error = "nnz exceeds int32"; return KNP_E_MESH; }
@@ -327,11 +330,13 @@ int knp_build_graph(const knp_mesh_desc* m, KnpHostGraph& g) {
             int32_t* ci = &g.colind[g.rowptr[(size_t)4 * n + f]];
             for (int q = 0; q < deg; ++q) { ci[2 * q] = 4 * g.pair_col[p0 + q] + f; ci[2 * q + 1] = 4 * g.pair_col[p0 + q] + 3; }
             for (int r = 0; r < x; ++r) ci[2 * deg + r] = 4 * cross[r] + 3;
+            if (x & 1) ci[2 * deg + x] = 4 * n + 3;   // padding entry, value stays 0
         }
         int32_t* ci = &g.colind[g.rowptr[(size_t)4 * n + 3]];
         for (int q = 0; q < deg; ++q)
             for (int f = 0; f < 4; ++f) ci[4 * q + f] = 4 * g.pair_col[p0 + q] + f;
         for (int r = 0; r < x; ++r) ci[4 * deg + r] = 4 * cross[r] + 3;
+        if (x & 1) ci[4 * deg + x] = 4 * n + 3;
     }
     return KNP_OK;
 }

@@ -661,6 +661,7 @@ class OracleKNPEMI:
                     self.update_t_mod()
                     self.update_gating(mdl)
             A = self.assemble_A()
+            self.current_A = A
             b = self.assemble_b()
             if step == 1:
                 assert np.abs(A @ ns).max() <= 1e-10 * np.abs(A).max() * 100, "ns not in null space"
@@ -851,6 +852,43 @@ def pc_amg_vcycle(levels, coarse_inv, pre=1, post=1, cheby_degree=2):
         return x
 
     return lambda r: cycle(0, r)
+
+
+def pc_btcc(o, hier_k, hier_p, pre=1, post=1, cheby_degree=2):
+    """NumPy restatement of the library's block lower-triangular preconditioner (KNP_PC_AMG_BT):
+        z_k   = V_k r                                         (V-cycle of the ion-field hierarchy)
+        t_phi = r_phi - sum_j z_j r_kj + M (sum_j z_j z_kj)   (== r_phi - A_{phi,k} z_k for exact ion solves,
+                 because A_{phi,kj} = z_j (A_{kj,kj} - M); this form does not amplify the V-cycle error)
+        z_phi = V_phi t + cc * t_phi,  cc = psi / (sum_j z_j^2 k_j) / M_lumped   (Cahouet-Chabard Schur term)
+    The hierarchies are data built by the host setup and passed in by the test."""
+    Vk = pc_amg_vcycle(hier_k.levels, hier_k.coarse_inv, pre, post, cheby_degree)
+    Vp = pc_amg_vcycle(hier_p.levels, hier_p.coarse_inv, pre, post, cheby_degree)
+    n = o.n_dof
+    nn = o.lay.n_nodes
+    nv1 = o.dim + 1
+    # same-side P1 mass matrix on nodes
+    Mn = sp.coo_matrix((o.Mloc.ravel(), (o.rowsA.ravel(), o.colsA.ravel())), shape=(nn, nn)).tocsr()
+    ML = np.asarray(Mn.sum(axis=1)).ravel()
+    pidx = np.arange(3, n, 4)
+    zz = np.array(o.p.z)
+
+    def apply(r):
+        p = o.p
+        s = np.zeros(nn)
+        for side, nodes in ((0, o.lay.node_i), (1, o.lay.node_e)):
+            v = np.nonzero(nodes >= 0)[0]
+            s[nodes[v]] = sum(p.z[j] ** 2 * o.k[side][j][v] for j in range(3))
+        cc = p.psi / (s * ML)
+        z = Vk(r)
+        z[pidx] = 0.0
+        zr = sum(zz[j] * r[j::4] for j in range(3))
+        zk = sum(zz[j] * z[j::4] for j in range(3))
+        t = np.zeros_like(r)
+        t[pidx] = r[pidx] - zr + Mn @ zk
+        w = Vp(t)
+        z[pidx] = w[pidx] + cc * t[pidx]
+        return z
+    return apply
 
 
 # --------------------------------------------------------------------------------------

@@ -185,6 +185,30 @@ def test_gmres_amg_iterates_match_oracle_gmres(N, kind, steps):
         assert np.max(np.abs(x[f::4] - xo[f::4])) <= 1e-9 * np.max(np.abs(xo[f::4])), f
 
 
+@pytest.mark.parametrize("N,kind,steps", [(32, "square", 3), (8, "cube", 2)])
+def test_btcc_iterates_match_oracle(N, kind, steps):
+    """Block-triangular preconditioner (pc_type btcc): same algorithm restated in NumPy on the same two
+    hierarchies -> same iteration counts, same iterates; and it converges to the LU solution."""
+    import knpemi_oracle as K
+    cfg = ci_config(N=N, steps=steps, rtol=1e-9, kind=kind, pc="btcc")
+    cfg["solver"]["ksp_settings"]["amg_coarse_size"] = 150
+    s = run_native(cfg)
+    hk, hp = s.hierarchies
+    assert len(hk.levels) >= 2 and len(hp.levels) >= 2
+    o = make_oracle(N, kind)
+    xo, its = o.run(steps, solver="gmres", rtol=1e-9,
+                    pc=lambda P: K.pc_btcc(o, hk, hp, s.amg_pre, s.amg_post, s.amg_cheby_degree))
+    assert its == list(s.iterations)
+    assert max(its) <= (6 if kind == "square" else 20)
+    x = s.backend.x.cpu().numpy()
+    for f in range(4):
+        assert np.max(np.abs(x[f::4] - xo[f::4])) <= 1e-9 * np.max(np.abs(xo[f::4])), f
+    ol = run_oracle(N=N, steps=steps, kind=kind)
+    ni, ne = s.potential_norms()
+    oi, oe = ol.potential_norms()
+    assert abs(ni - oi) <= 2e-6 * oi
+
+
 def test_ci_problem_against_reference_pins():
     """The reference's own CI problem (32x32, 10 steps, GMRES rtol 1e-9, AMG in place of BoomerAMG)."""
     s = run_native(ci_config(N=32, steps=10, rtol=1e-9))
