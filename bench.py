@@ -158,6 +158,16 @@ def main():
                 "avg_launch_us": avg_s * 1e6, "launches": int(spmv_n),
                 "note": "working set of the 512^2 case (~150 MB matrix) largely stays in the 256 MB Infinity Cache"
                         if be.nnz * 8 < 200e6 else "matrix exceeds the Infinity Cache"}
+        # HBM traffic per launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the gfx950
+        # 16-B-load correction + WRITE_SIZE; collected by `rocprofv3 --pmc` in separate runs of this command)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            ent = pmc.get(args.workload, {})
+            hit = [v for k, v in ent.items() if k.startswith("void k_spmv_node") and k.endswith(", 0>")]
+            if hit and node_kernel and world == 1:
+                roof["traffic"] = hit[0]["hbm_bytes_corrected"]
+        except Exception:      # noqa: BLE001
+            pass
 
     norms = solver.potential_norms()
 
