@@ -54,9 +54,13 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=os.environ.get("KNP_DIST_BACKEND", "nccl"), rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank) if os.environ.get("KNP_DIST_BACKEND", "nccl") == "nccl" else None)
+        backend = os.environ.get("KNP_DIST_BACKEND", "nccl")      # "gloo": rehearsal with several ranks on one GPU
+        dev_index = local_rank % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"

@@ -142,6 +142,9 @@ enum {
 /* communication hooks (multi-GPU); both receive DEVICE pointers */
 typedef int (*knp_halo_fn)(void* user, double* x_local);              /* fill ghost part of x */
 typedef int (*knp_allreduce_fn)(void* user, double* buf, int32_t n);  /* in-place SUM over ranks */
+/* per-level exchange of a distributed AMG hierarchy; op 0: forward halo (fill the ghost entries of a level vector),
+ * op 1: reverse halo (add ghost entries to their owners), op 2: all-reduce SUM of a replicated coarse vector */
+typedef int (*knp_level_comm_fn)(void* user, int32_t hier, int32_t level, int32_t op, double* vec);
 
 /* ---- lifetime ---- */
 int knp_create(knp_ctx** out, const knp_mesh_desc* mesh);
@@ -149,6 +152,7 @@ int knp_destroy(knp_ctx* ctx);
 const char* knp_last_error(const knp_ctx* ctx);
 int knp_set_stream(knp_ctx* ctx, void* hip_stream);
 int knp_set_comm(knp_ctx* ctx, knp_halo_fn halo, knp_allreduce_fn allreduce, void* user);
+int knp_set_level_comm(knp_ctx* ctx, knp_level_comm_fn fn);
 
 /* ---- description ---- */
 int knp_get_sizes(const knp_ctx* ctx, int64_t* sizes /* host [KNP_SZ_COUNT] */);
@@ -193,6 +197,9 @@ int knp_amg_set_level(knp_ctx* ctx, int32_t hier, int32_t level, int32_t n_rows,
                       int32_t n_coarse,
                       const int32_t* P_rowptr, const int32_t* P_colind, const double* P_vals,
                       const int32_t* R_rowptr, const int32_t* R_colind, const double* R_vals);
+/* distributed hierarchy: `distributed` != 0 -> the level operator has ghost columns (n_cols_halo local columns);
+ * repl_n > 0 -> the next level is replicated on all ranks with repl_n unknowns */
+int knp_amg_set_level_mode(knp_ctx* ctx, int32_t hier, int32_t level, int32_t distributed, int32_t repl_n);
 int knp_amg_set_coarse(knp_ctx* ctx, int32_t hier, int32_t n, const double* dense_inverse /* host [n*n] row-major */);
 /* level 0 == the library's own P (owned block): use its pair-major storage and node kernels instead of the uploaded
  * CSR. mode: 0 off, 1 all four fields, 2 ion fields only, 3 potential only */

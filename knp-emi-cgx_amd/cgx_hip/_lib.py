@@ -51,6 +51,7 @@ class FieldsOut(C.Structure):
 
 HALO_FN = C.CFUNCTYPE(C.c_int, vp, vp)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, vp, vp, C.c_int32)
+LEVEL_COMM_FN = C.CFUNCTYPE(C.c_int, vp, C.c_int32, C.c_int32, C.c_int32, vp)
 
 # every symbol include/knpemi_hip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
@@ -59,6 +60,7 @@ SIGNATURES = {
     "knp_last_error": (C.c_char_p, [vp]),
     "knp_set_stream": (C.c_int, [vp, vp]),
     "knp_set_comm": (C.c_int, [vp, HALO_FN, ALLREDUCE_FN, vp]),
+    "knp_set_level_comm": (C.c_int, [vp, LEVEL_COMM_FN]),
     "knp_get_sizes": (C.c_int, [vp, i64p]),
     "knp_get_layout": (C.c_int, [vp, i32p, i32p]),
     "knp_get_csr_pattern": (C.c_int, [vp, i32p, i32p]),
@@ -82,6 +84,7 @@ SIGNATURES = {
     "knp_amg_reset": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "knp_amg_set_level": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, i32p, i32p, f64p, f64p, C.c_double,
                                     C.c_int32, i32p, i32p, f64p, i32p, i32p, f64p]),
+    "knp_amg_set_level_mode": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "knp_amg_set_coarse": (C.c_int, [vp, C.c_int32, C.c_int32, f64p]),
     "knp_amg_use_native_level0": (C.c_int, [vp, C.c_int32, C.c_int32]),
     "knp_gmres_solve": (C.c_int, [vp, vp, vp, C.c_double, C.c_double, C.c_int32, C.c_int32, i32p, f64p, i32p]),

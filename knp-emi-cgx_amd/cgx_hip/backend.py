@@ -95,10 +95,14 @@ class Backend:
         # communication hooks
         self.halo = HaloPlan(problem.comm, lm, self.node_i, self.node_e, self.device)
         self._views = {}
+        self.level_halos = {}          # (hier, level) -> LevelHalo of a distributed AMG hierarchy
+        self.level_repl = {}           # (hier, level) -> replicated coarse size
         if problem.comm.size > 1:
             self._halo_cb = _lib.HALO_FN(guarded(self._halo))
             self._ar_cb = _lib.ALLREDUCE_FN(guarded(self._allreduce))
             self.check(self.lib.knp_set_comm(self.ctx, self._halo_cb, self._ar_cb, None))
+            self._lc_cb = _lib.LEVEL_COMM_FN(guarded(self._level_comm))
+            self.check(self.lib.knp_set_level_comm(self.ctx, self._lc_cb))
         if getattr(problem, "programs", None):
             self.upload_programs()
         self.setup_deflation()
@@ -109,7 +113,7 @@ class Backend:
         p = self.p
         lm = p.local_mesh
         d = getattr(lm, "defl", None)
-        if p.comm.size == 1 or not d:
+        if p.comm.size == 1 or not d or getattr(self, "_skip_deflation", False):
             return
         m = int(d["n_modes"])
         nvo = lm.n_vertices_owned
@@ -159,6 +163,32 @@ class Backend:
 
     def _allreduce(self, user, ptr, n):
         all_reduce_sum_(self._view(ptr, n), self.p.comm)
+
+    def _level_comm(self, user, hier, level, op, ptr):
+        if op == 2:
+            all_reduce_sum_(self._view(ptr, self.level_repl[(hier, level)]), self.p.comm)
+            return
+        h = self.level_halos[(hier, level)]
+        x = self._view(ptr, h.n_loc)
+        if op == 0:
+            h.forward(x)
+        else:
+            h.reverse_add(x)
+
+    def dof_level_halo(self):
+        """LevelHalo of the fine DoF vector layout (level 0 of a distributed hierarchy)."""
+        from .dist_amg import LevelHalo
+        p = self.p
+        comm = p.comm
+        counts = comm.all_gather_object(int(self.n_dof_owned))
+        offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        start = int(offs[comm.rank])
+        ids = torch.zeros(self.n_dof_local, dtype=torch.float64, device=self.device)
+        ids[:self.n_dof_owned] = torch.arange(start, start + self.n_dof_owned, dtype=torch.float64, device=self.device)
+        self.halo.exchange(ids)
+        ghost_gid = np.rint(ids[self.n_dof_owned:].cpu().numpy()).astype(np.int64)
+        ghost_owner = (np.searchsorted(offs, ghost_gid, side="right") - 1).astype(np.int64)
+        return LevelHalo(comm, self.n_dof_owned, ghost_gid, ghost_owner, start, self.device), start, ghost_gid, ghost_owner
 
     def set_params(self):
         p = self.p

@@ -29,7 +29,9 @@ import time
 import numpy as np
 import torch
 
-from . import _lib, amg
+import os
+
+from . import _lib, amg, dist_amg
 from .ionic_models import HodgkinHuxley
 from .problem import ProblemKNPEMI
 
@@ -78,6 +80,7 @@ class SolverKNPEMI:
     amg_pre = 1
     amg_post = 1
     amg_coarse_size = 2500
+    amg_replicate_below = 40000
 
     def __init__(self, problem: ProblemKNPEMI, solver_config: dict):
         self.problem = problem
@@ -109,7 +112,7 @@ class SolverKNPEMI:
             if "ksp_max_it" in ks: self.ksp_max_it = int(ks["ksp_max_it"])
             if "gmres_restart" in ks: self.gmres_restart = int(ks["gmres_restart"])
             if "strict" in ks: self.strict = bool(ks["strict"])
-            for k in ("amg_theta", "amg_cheby_degree", "amg_pre", "amg_post", "amg_coarse_size"):
+            for k in ("amg_theta", "amg_cheby_degree", "amg_pre", "amg_post", "amg_coarse_size", "amg_replicate_below"):
                 if k in ks: setattr(self, k, type(getattr(self, k))(ks[k]))
         if self.ksp_type != "gmres":
             raise NotImplementedError(f"ksp_type '{self.ksp_type}': only 'gmres' is implemented natively.")
@@ -142,6 +145,10 @@ class SolverKNPEMI:
         if self._pc_kind in (_lib.PC_AMG, _lib.PC_AMG_BT):
             tic = time.perf_counter()
             P = be.precond_csr()
+            if self.comm.size > 1 and os.environ.get("KNP_DIST_PC", "global") != "bj":
+                self._assemble_distributed_amg(P)
+                self.P_ = "device CSR (see Backend.precond_csr)"
+                return
             P = P[:, :be.n_dof_owned].tocsr()          # per-rank block (block-Jacobi across GPUs)
             if self._pc_kind == _lib.PC_AMG:
                 self.hierarchy = amg.build_hierarchy(P, theta=self.amg_theta, coarse_size=self.amg_coarse_size)
@@ -160,6 +167,30 @@ class SolverKNPEMI:
             self.amg_setup_time = time.perf_counter() - tic
             self.print(f"AMG hierarchies: {[h.describe() for h in self.hierarchies]} (host setup {self.amg_setup_time:0.3f} s)")
         self.P_ = "device CSR (see Backend.precond_csr)"
+
+    def _assemble_distributed_amg(self, P_loc):
+        """Multi-GPU: one global smoothed-aggregation hierarchy (cgx_hip/dist_amg.py) instead of per-GPU blocks."""
+        be = self.backend
+        tic = time.perf_counter()
+        halo0, start, ggid, gown = be.dof_level_halo()
+        specs = [((0, 1, 2, 3), 1)] if self._pc_kind == _lib.PC_AMG else [((0, 1, 2), 2), ((3,), 3)]
+        self.hierarchies = []
+        for index, (fields, native_mode) in enumerate(specs):
+            Pm = P_loc if len(fields) == 4 else dist_amg.restrict_to_fields_rect(P_loc, fields)
+            levels, tail = dist_amg.build_distributed_hierarchy(self.comm, Pm, halo0, start, ggid, gown, theta=self.amg_theta,
+                                                                coarse_size=self.amg_coarse_size,
+                                                                replicate_below=self.amg_replicate_below, device=be.device)
+            dist_amg.upload(be.lib, be.ctx, be.check, levels, tail, self.amg_pre, self.amg_post, self.amg_cheby_degree, index=index)
+            be.check(be.lib.knp_amg_use_native_level0(be.ctx, index, native_mode))
+            for l, L in enumerate(levels):
+                be.level_halos[(index, l)] = L.halo
+                if L.replicated:
+                    be.level_repl[(index, l)] = int(L.repl_n)
+            self.hierarchies.append((levels, tail))
+            self.print(f"distributed AMG hierarchy {index}: {dist_amg.describe(levels, tail, self.comm)}")
+        self.hierarchy = self.hierarchies[0]
+        be.check(be.lib.knp_set_deflation(be.ctx, 0, None, None))     # the global coarse levels carry those modes
+        self.amg_setup_time = time.perf_counter() - tic
 
     def reassemble_preconditioner(self):
         self.print("Re-assembling preconditioner ...")

@@ -58,6 +58,9 @@ struct KnpProgram {
 
 struct KnpAmgLevel {
     int n = 0, n_coarse = 0;
+    int n_loc = 0;   // local columns = owned + ghost (== n on one GPU)
+    int dist = 0;    // operator has ghost columns: forward halo before every application
+    int repl_n = 0;  // > 0: the next level is replicated on all ranks with this many unknowns (all-reduce after restriction)
     int32_t *A_rp = nullptr, *A_ci = nullptr;
     double* A_v = nullptr;
     double* inv_diag = nullptr;
@@ -160,6 +163,7 @@ struct knp_ctx {
     // comm
     knp_halo_fn halo = nullptr;
     knp_allreduce_fn allreduce = nullptr;
+    knp_level_comm_fn level_comm = nullptr;
     void* comm_user = nullptr;
     // profiling
     int prof_on = 0;

@@ -583,7 +583,7 @@ static void launch_spmv_node(hipStream_t st, int G, int n_nodes, const int32_t* 
 // ------------------------------------------------------------------------------------------
 template <int G, int MODE, int FM>   // FM field mask: 0 all four fields, 1 ion fields only, 2 potential only
 __global__ void __launch_bounds__(NT)
-k_pnode(int n_nodes, const int32_t* __restrict__ pair_ptr, const int32_t* __restrict__ pair_col,
+k_pnode(int n_nodes, int n_col_nodes, const int32_t* __restrict__ pair_ptr, const int32_t* __restrict__ pair_col,
         const double* __restrict__ pv, const double* __restrict__ dinv, const double* __restrict__ b,
         const double* __restrict__ xin, double c1, double c2, double* __restrict__ d, double* __restrict__ xout) {
     const int node = (blockIdx.x * NT + threadIdx.x) / G;
@@ -594,7 +594,7 @@ k_pnode(int n_nodes, const int32_t* __restrict__ pair_ptr, const int32_t* __rest
         const int deg = pair_ptr[node + 1] - p0;
         for (int q = lane; q < deg; q += G) {
             const int nb = pair_col[p0 + q];
-            if (nb < n_nodes) {
+            if (nb < n_col_nodes) {
                 const double2 xb = *reinterpret_cast<const double2*>(xin + 4 * (size_t)nb + 2);
                 const double2 c = *reinterpret_cast<const double2*>(pv + 4 * (size_t)(p0 + q) + 2);
                 if (FM != 2) {
@@ -645,22 +645,22 @@ k_pnode(int n_nodes, const int32_t* __restrict__ pair_ptr, const int32_t* __rest
     }
 }
 template <int MODE, int FM>
-static void launch_pnode_fm(hipStream_t st, int G, int n_nodes, const int32_t* pp, const int32_t* pc, const double* pv,
+static void launch_pnode_fm(hipStream_t st, int G, int n_nodes, int ncn, const int32_t* pp, const int32_t* pc, const double* pv,
                             const double* dinv, const double* b, const double* xin, double c1, double c2, double* d, double* xout) {
     switch (G) {
-        case 4: hipLaunchKernelGGL((k_pnode<4, MODE, FM>), dim3(nblocks((int64_t)n_nodes * 4)), dim3(NT), 0, st, n_nodes, pp, pc, pv, dinv, b, xin, c1, c2, d, xout); break;
-        case 8: hipLaunchKernelGGL((k_pnode<8, MODE, FM>), dim3(nblocks((int64_t)n_nodes * 8)), dim3(NT), 0, st, n_nodes, pp, pc, pv, dinv, b, xin, c1, c2, d, xout); break;
-        case 16: hipLaunchKernelGGL((k_pnode<16, MODE, FM>), dim3(nblocks((int64_t)n_nodes * 16)), dim3(NT), 0, st, n_nodes, pp, pc, pv, dinv, b, xin, c1, c2, d, xout); break;
-        default: hipLaunchKernelGGL((k_pnode<32, MODE, FM>), dim3(nblocks((int64_t)n_nodes * 32)), dim3(NT), 0, st, n_nodes, pp, pc, pv, dinv, b, xin, c1, c2, d, xout); break;
+        case 4: hipLaunchKernelGGL((k_pnode<4, MODE, FM>), dim3(nblocks((int64_t)n_nodes * 4)), dim3(NT), 0, st, n_nodes, ncn, pp, pc, pv, dinv, b, xin, c1, c2, d, xout); break;
+        case 8: hipLaunchKernelGGL((k_pnode<8, MODE, FM>), dim3(nblocks((int64_t)n_nodes * 8)), dim3(NT), 0, st, n_nodes, ncn, pp, pc, pv, dinv, b, xin, c1, c2, d, xout); break;
+        case 16: hipLaunchKernelGGL((k_pnode<16, MODE, FM>), dim3(nblocks((int64_t)n_nodes * 16)), dim3(NT), 0, st, n_nodes, ncn, pp, pc, pv, dinv, b, xin, c1, c2, d, xout); break;
+        default: hipLaunchKernelGGL((k_pnode<32, MODE, FM>), dim3(nblocks((int64_t)n_nodes * 32)), dim3(NT), 0, st, n_nodes, ncn, pp, pc, pv, dinv, b, xin, c1, c2, d, xout); break;
     }
 }
 template <int MODE>
-static void launch_pnode(hipStream_t st, int fm, int G, int n_nodes, const int32_t* pp, const int32_t* pc, const double* pv,
+static void launch_pnode(hipStream_t st, int fm, int G, int n_nodes, int ncn, const int32_t* pp, const int32_t* pc, const double* pv,
                          const double* dinv, const double* b, const double* xin, double c1, double c2, double* d, double* xout) {
     if (n_nodes <= 0) return;
-    if (fm == 1) launch_pnode_fm<MODE, 1>(st, G, n_nodes, pp, pc, pv, dinv, b, xin, c1, c2, d, xout);
-    else if (fm == 2) launch_pnode_fm<MODE, 2>(st, G, n_nodes, pp, pc, pv, dinv, b, xin, c1, c2, d, xout);
-    else launch_pnode_fm<MODE, 0>(st, G, n_nodes, pp, pc, pv, dinv, b, xin, c1, c2, d, xout);
+    if (fm == 1) launch_pnode_fm<MODE, 1>(st, G, n_nodes, ncn, pp, pc, pv, dinv, b, xin, c1, c2, d, xout);
+    else if (fm == 2) launch_pnode_fm<MODE, 2>(st, G, n_nodes, ncn, pp, pc, pv, dinv, b, xin, c1, c2, d, xout);
+    else launch_pnode_fm<MODE, 0>(st, G, n_nodes, ncn, pp, pc, pv, dinv, b, xin, c1, c2, d, xout);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1805,16 +1805,16 @@ int knp_amg_set_level(knp_ctx* ctx, int32_t hier, int32_t level, int32_t n_rows,
                       const int32_t* P_rp, const int32_t* P_ci, const double* P_v, const int32_t* R_rp, const int32_t* R_ci,
                       const double* R_v) {
     CHECK_CTX(ctx);
-    (void)n_cols_halo;
     if (hier < 0 || hier >= KNP_MAX_HIER) { ctx->err = "bad hierarchy index"; return KNP_E_ARG; }
     KnpAmgHier& H = ctx->hier[hier];
     if (level < 0 || level >= H.levels || n_rows <= 0 || !A_rp || !A_ci || !A_v || !inv_diag) { ctx->err = "bad AMG level arguments"; return KNP_E_ARG; }
     if (level == 0 && n_rows != ctx->n_dof_owned) { ctx->err = "AMG level 0 must have n_dof_owned rows"; return KNP_E_ARG; }
     KnpAmgLevel& L = H.lv[level];
     const int64_t nnzA = A_rp[n_rows];
+    const int n_loc = std::max(n_cols_halo, n_rows);
     for (int64_t k = 0; k < nnzA; ++k)
-        if (A_ci[k] < 0 || A_ci[k] >= n_rows) { ctx->err = "AMG level matrix column out of range"; return KNP_E_ARG; }
-    L.n = n_rows; L.n_coarse = n_coarse; L.lambda_max = lambda_max;
+        if (A_ci[k] < 0 || A_ci[k] >= n_loc) { ctx->err = "AMG level matrix column out of range"; return KNP_E_ARG; }
+    L.n = n_rows; L.n_loc = n_loc; L.n_coarse = n_coarse; L.lambda_max = lambda_max;
     KCHK(dev_upload_raw(ctx, &L.A_rp, A_rp, (size_t)n_rows + 1));
     KCHK(dev_upload_raw(ctx, &L.A_ci, A_ci, (size_t)nnzA));
     KCHK(dev_upload_raw(ctx, &L.A_v, A_v, (size_t)nnzA));
@@ -1836,14 +1836,28 @@ int knp_amg_set_level(knp_ctx* ctx, int32_t hier, int32_t level, int32_t n_rows,
         L.P_lanes = pick_lanes((double)nnzP / n_rows);
         L.R_lanes = pick_lanes((double)nnzR / n_coarse);
     }
-    HIPCHK(hipMalloc((void**)&L.x, (size_t)n_rows * sizeof(double)));
-    HIPCHK(hipMalloc((void**)&L.b, (size_t)n_rows * sizeof(double)));
-    HIPCHK(hipMalloc((void**)&L.r, (size_t)n_rows * sizeof(double)));
-    HIPCHK(hipMalloc((void**)&L.d, (size_t)n_rows * sizeof(double)));
-    HIPCHK(hipMalloc((void**)&L.r2, (size_t)n_rows * sizeof(double)));
-    HIPCHK(hipMemset(L.r2, 0, (size_t)n_rows * sizeof(double)));
-    HIPCHK(hipMemset(L.x, 0, (size_t)n_rows * sizeof(double)));
-    HIPCHK(hipMemset(L.d, 0, (size_t)n_rows * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&L.x, (size_t)n_loc * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&L.b, (size_t)n_loc * sizeof(double)));
+    HIPCHK(hipMemset(L.b, 0, (size_t)n_loc * sizeof(double)));
+    HIPCHK(hipMemset(L.r, 0, 0));
+    HIPCHK(hipMalloc((void**)&L.r, (size_t)n_loc * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&L.d, (size_t)n_loc * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&L.r2, (size_t)n_loc * sizeof(double)));
+    HIPCHK(hipMemset(L.r2, 0, (size_t)n_loc * sizeof(double)));
+    HIPCHK(hipMemset(L.x, 0, (size_t)n_loc * sizeof(double)));
+    HIPCHK(hipMemset(L.d, 0, (size_t)n_loc * sizeof(double)));
+    return KNP_OK;
+}
+int knp_amg_set_level_mode(knp_ctx* ctx, int32_t hier, int32_t level, int32_t distributed, int32_t repl_n) {
+    CHECK_CTX(ctx);
+    if (hier < 0 || hier >= KNP_MAX_HIER || level < 0 || level >= ctx->hier[hier].levels || repl_n < 0) { ctx->err = "bad arguments"; return KNP_E_ARG; }
+    ctx->hier[hier].lv[level].dist = distributed ? 1 : 0;
+    ctx->hier[hier].lv[level].repl_n = repl_n;
+    return KNP_OK;
+}
+int knp_set_level_comm(knp_ctx* ctx, knp_level_comm_fn fn) {
+    CHECK_CTX(ctx);
+    ctx->level_comm = fn;
     return KNP_OK;
 }
 int knp_amg_use_native_level0(knp_ctx* ctx, int32_t hier, int32_t mode) {
@@ -1876,9 +1890,12 @@ static void amg_smooth(knp_ctx* ctx, KnpAmgHier& H, int l, const double* b, doub
     hipStream_t st = ctx->stream;
     auto other = [&](double* p) { return p == bufA ? bufB : bufA; };
     const bool native0 = (l == 0) && H.native0 > 0;
-    auto step = [&](const double* xin, double c1, double c2, double* out) {
+    const int hidx = (int)(&H - ctx->hier);
+    auto step = [&](double* xin, double c1, double c2, double* out) {
+        if (L.dist && ctx->level_comm) (void)ctx->level_comm(ctx->comm_user, hidx, l, 0, xin);
         if (native0)
-            launch_pnode<0>(st, H.native0 - 1, ctx->spmv_group > 0 ? ctx->spmv_group : 8, ctx->g.n_nodes_owned, ctx->d_pair_ptr,
+            launch_pnode<0>(st, H.native0 - 1, ctx->spmv_group > 0 ? ctx->spmv_group : 8, ctx->g.n_nodes_owned,
+                            L.dist ? ctx->g.n_nodes : ctx->g.n_nodes_owned, ctx->d_pair_ptr,
                             ctx->d_pair_col, ctx->d_p_vals, L.inv_diag, b, xin, c1, c2, L.d, out);
         else
             launch_cheby(st, L.A_lanes, L.n, L.A_rp, L.A_ci, L.A_v, L.inv_diag, b, xin, c1, c2, L.d, out);
@@ -1938,13 +1955,21 @@ static double* amg_vcycle(knp_ctx* ctx, KnpAmgHier& H, int l, const double* b, d
     for (int sw = 0; sw < H.pre; ++sw) { amg_smooth(ctx, H, l, b, &cur, bufA, bufB, zero); zero = false; }
     if (zero) hipLaunchKernelGGL(k_fill, dim3(std::min(nblocks(L.n), 2048)), dim3(NT), 0, st, L.n, 0.0, cur);
     // r = b - A x ; b_c = R r
+    const int hidx = (int)(&H - ctx->hier);
+    if (L.dist && ctx->level_comm) (void)ctx->level_comm(ctx->comm_user, hidx, l, 0, cur);
     if (l == 0 && H.native0 > 0)
-        launch_pnode<1>(st, H.native0 - 1, ctx->spmv_group > 0 ? ctx->spmv_group : 8, ctx->g.n_nodes_owned, ctx->d_pair_ptr,
+        launch_pnode<1>(st, H.native0 - 1, ctx->spmv_group > 0 ? ctx->spmv_group : 8, ctx->g.n_nodes_owned,
+                        L.dist ? ctx->g.n_nodes : ctx->g.n_nodes_owned, ctx->d_pair_ptr,
                         ctx->d_pair_col, ctx->d_p_vals, L.inv_diag, b, cur, 0.0, 0.0, L.d, L.r);
     else
         launch_spmv<1>(st, L.A_lanes, L.n, L.A_rp, L.A_ci, L.A_v, cur, b, L.r);
     launch_spmv<0>(st, L.R_lanes, nc, L.R_rp, L.R_ci, L.R_v, L.r, nullptr, C.b);
+    if (ctx->level_comm) {
+        if (L.repl_n > 0) (void)ctx->level_comm(ctx->comm_user, hidx, l, 2, C.b);           // replicate the coarse rhs
+        else if (C.dist) (void)ctx->level_comm(ctx->comm_user, hidx, l + 1, 1, C.b);        // ghost rows -> owners
+    }
     double* xc = amg_vcycle(ctx, H, l + 1, C.b, nullptr);
+    if (C.dist && ctx->level_comm && L.repl_n == 0) (void)ctx->level_comm(ctx->comm_user, hidx, l + 1, 0, xc);
     // x += P x_c (fused)
     launch_spmv<2>(st, L.P_lanes, L.n, L.P_rp, L.P_ci, L.P_v, xc, nullptr, cur);
     for (int sw = 0; sw < H.post; ++sw) amg_smooth(ctx, H, l, b, &cur, bufA, bufB, false);
@@ -1954,8 +1979,11 @@ static double* amg_vcycle(knp_ctx* ctx, KnpAmgHier& H, int l, const double* b, d
 static int check_hier(knp_ctx* ctx, int h) {
     KnpAmgHier& H = ctx->hier[h];
     if (H.levels < 1 || H.lv[0].n != ctx->n_dof_owned) { ctx->err = "AMG hierarchy " + std::to_string(h) + " not supplied"; return KNP_E_STATE; }
-    for (int l = 0; l < H.levels - 1; ++l)
-        if (H.lv[l].n_coarse != H.lv[l + 1].n) { ctx->err = "AMG level sizes inconsistent"; return KNP_E_STATE; }
+    for (int l = 0; l < H.levels - 1; ++l) {
+        const int expect = H.lv[l].repl_n > 0 ? H.lv[l + 1].n : H.lv[l + 1].n_loc;   // rows of R = coarse local size
+        if (H.lv[l].n_coarse != expect) { ctx->err = "AMG level sizes inconsistent"; return KNP_E_STATE; }
+        if (H.lv[l].repl_n > 0 && H.lv[l].repl_n != H.lv[l + 1].n) { ctx->err = "replicated coarse size mismatch"; return KNP_E_STATE; }
+    }
     if (H.nc > 0 && H.nc != H.lv[H.levels - 1].n) { ctx->err = "AMG coarse inverse size mismatch"; return KNP_E_STATE; }
     return KNP_OK;
 }
