@@ -178,7 +178,7 @@ def main():
     # ---- CPU baseline: the oracle (NumPy/SciPy restatement, 1 core) on a bounded sample --------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(kind, N, args.models, args.rtol, args.cpu_steps)
+        cpu = cpu_baseline(kind, N, args.models, args.rtol, args.cpu_steps, args.pc, solver)
 
     if rank == 0:
         out = {
@@ -202,9 +202,9 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(kind, N, models, rtol, steps):
-    """Oracle timed on the host: same mesh, same physics, same algorithm class (GMRES(30), left PC,
-    the same AMG hierarchy construction applied by the NumPy V-cycle), single thread."""
+def cpu_baseline(kind, N, models, rtol, steps, pc, solver):
+    """Oracle timed on the host: same mesh, same physics, same algorithm (GMRES(30), left PC, the same
+    AMG construction and cycle parameters, applied by the NumPy V-cycle), single thread."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import knpemi_oracle as K
     from cgx_hip import amg
@@ -212,22 +212,26 @@ def cpu_baseline(kind, N, models, rtol, steps):
     mk = K.make_square if kind == "square" else K.make_cube
     mdl = K.CI_MODELS() if models == "ci" else [K.Model("passive", (4,))]
     o = mk(N, models=mdl)
+    pre, post, deg = solver.amg_pre, solver.amg_post, solver.amg_cheby_degree
 
     def fac(P):
-        h = amg.build_hierarchy(P)
-        return K.pc_amg_vcycle(h.levels, h.coarse_inv, 1, 1, 2)
+        if pc == "btcc":
+            hk = amg.build_hierarchy(amg.restrict_to_fields(P, (0, 1, 2)), theta=solver.amg_theta, coarse_size=solver.amg_coarse_size)
+            hp = amg.build_hierarchy(amg.restrict_to_fields(P, (3,)), theta=solver.amg_theta, coarse_size=solver.amg_coarse_size)
+            return K.pc_btcc(o, hk, hp, pre, post, deg)
+        h = amg.build_hierarchy(P, theta=solver.amg_theta, coarse_size=solver.amg_coarse_size)
+        return K.pc_amg_vcycle(h.levels, h.coarse_inv, pre, post, deg)
     times = []
 
     def log(step, oo, x):
         times.append(time.perf_counter())
-    # setup (P, hierarchy) excluded like on the GPU side: run() builds it before the loop
     t_start = time.perf_counter()
-    o.run(steps + 1, solver="gmres", pc=fac, rtol=rtol, log=log)
-    # per-step time from step 2 on (step 1 includes the null-space check)
-    per = [(times[i] - times[i - 1]) for i in range(1, len(times))]
+    _, its = o.run(steps + 1, solver="gmres", pc=fac, rtol=rtol, log=log)
+    per = [(times[i] - times[i - 1]) for i in range(1, len(times))]      # step 1 (null-space check, setup) excluded
     sec = sum(per) / len(per)
     return {"value": o.n_dof / sec / 1e6, "unit": "MDoF/s", "cores": 1, "kind": "port",
-            "sample": f"{steps} implicit steps of the same {kind}{N} workload (NumPy/SciPy oracle, GMRES+AMG V-cycle in NumPy), "
+            "sample": f"{steps} implicit steps of the same {kind}{N} workload (NumPy/SciPy oracle: vectorised assembly, "
+                      f"GMRES(30)+{pc} with the NumPy V-cycle, {sum(its[1:]) / max(len(its) - 1, 1):.1f} its/step), "
                       f"{sec:.2f} s/step; total {time.perf_counter() - t_start:.1f} s incl. setup"}
 
 

@@ -76,7 +76,7 @@ class SolverKNPEMI:
     strict = False
     # native AMG parameters
     amg_theta = 0.08
-    amg_cheby_degree = 2
+    amg_cheby_degree = 1
     amg_pre = 1
     amg_post = 1
     amg_coarse_size = 2500

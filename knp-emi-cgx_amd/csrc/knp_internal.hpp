@@ -154,6 +154,11 @@ struct knp_ctx {
     double* h_red_dev = nullptr; // device-visible address of h_red (zero-copy read-back)
     double* mirror() const { return allreduce ? nullptr : h_red_dev; }
     int64_t phi_count_cached = -1;
+    int64_t* h_seq = nullptr;        // pinned sequence word published by the last reduction kernel of a read-back
+    int64_t* h_seq_dev = nullptr;
+    int64_t seq_counter = 0;
+    int asm_full = 0;                // KNP_ASM_FULL=1: rewrite the time-invariant blocks at every assembly
+    double asm_dt = -1.0;
     // deflation
     int defl_m = 0;
     int32_t* d_defl_mode = nullptr;

@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(NT) k_cell_means(int n_c, int nv1, const int32
 // ------------------------------------------------------------------------------------------
 // K1: volume blocks, one thread per node pair
 // ------------------------------------------------------------------------------------------
-template <bool PRECOND>
+template <bool PRECOND, bool TD_ONLY>   // TD_ONLY: write only the entries that depend on the previous solution
 __global__ void __launch_bounds__(NT)
 k_assemble_pairs(int64_t n_pairs, int n_c, DevParams P, const int32_t* __restrict__ pair_row,
                  const int32_t* __restrict__ pair_ptr, const uint8_t* __restrict__ node_side,
@@ -138,9 +138,11 @@ k_assemble_pairs(int64_t n_pairs, int n_c, DevParams P, const int32_t* __restric
             const double D = side ? P.De[j] : P.Di[j];
             const double z = P.z[j];
             const int rj = rowptr[4 * n + j];
-            vals[rj + 2 * q] = M + P.dt * D * K;
+            if (!TD_ONLY) {
+                vals[rj + 2 * q] = M + P.dt * D * K;          // (k,k):   time invariant
+                vals[rphi + 4 * q + j] = P.dt * z * D * K;    // (phi,k): time invariant
+            }
             vals[rj + 2 * q + 1] = P.dt * D * z / P.psi * S[j];
-            vals[rphi + 4 * q + j] = P.dt * z * D * K;
             phiphi += P.dt * D * z * z / P.psi * S[j];
         }
         vals[rphi + 4 * q + 3] = phiphi;
@@ -746,16 +748,20 @@ static int pick_lanes(double avg_nnz_per_row) {
 // K5/K6: orthogonalisation and vector kernels
 // ------------------------------------------------------------------------------------------
 // partial[(i)*RED_BLOCKS + blk] = sum over this block's elements of V_i . w, i = i0 .. i0+G-1 (< m)
-template <int G>
+// NS: additionally accumulate the sum of the potential entries of w into row `m` of partial -- the coefficient
+// of w along the (unnormalised) null-space vector, so that the gauge projection rides on the same reduction.
+template <int G, bool NS>
 __global__ void __launch_bounds__(NT)
 k_multi_dot(int n, int64_t ldv, int i0, int m, const double* __restrict__ V, const double* __restrict__ w,
             double* __restrict__ partial) {
     __shared__ double sm[NT / 64];
     double acc[G];
+    double ans = 0.0;
 #pragma unroll
     for (int g = 0; g < G; ++g) acc[g] = 0.0;
     for (int e = blockIdx.x * NT + threadIdx.x; e < n; e += gridDim.x * NT) {
         const double we = w[e];
+        if (NS && (e & 3) == 3) ans += we;
 #pragma unroll
         for (int g = 0; g < G; ++g)
             if (i0 + g < m) acc[g] += V[(int64_t)(i0 + g) * ldv + e] * we;
@@ -765,11 +771,16 @@ k_multi_dot(int n, int64_t ldv, int i0, int m, const double* __restrict__ V, con
         double r = block_sum(acc[g], sm);
         if (threadIdx.x == 0 && i0 + g < m) partial[(size_t)(i0 + g) * RED_BLOCKS + blockIdx.x] = r;
     }
+    if (NS) {
+        double r = block_sum(ans, sm);
+        if (threadIdx.x == 0) partial[(size_t)m * RED_BLOCKS + blockIdx.x] = r;
+    }
 }
 
 // out[slot0 + i] = sum_b partial[i*RED_BLOCKS + b], one block per i
 __global__ void __launch_bounds__(NT) k_reduce_partials(int nb, const double* __restrict__ partial,
-                                                        double* __restrict__ out, int slot0, double* host_mirror) {
+                                                        double* __restrict__ out, int slot0, double* host_mirror,
+                                                        volatile int64_t* seq = nullptr, int64_t seq_val = 0) {
     __shared__ double sm[NT / 64];
     const int i = blockIdx.x;
     double a = 0.0;
@@ -778,17 +789,24 @@ __global__ void __launch_bounds__(NT) k_reduce_partials(int nb, const double* __
     if (threadIdx.x == 0) {
         out[slot0 + i] = a;
         if (host_mirror) host_mirror[slot0 + i] = a;   // pinned, device-visible: no copy kernel for the read-back
+        if (seq) {                                     // single-block launches only: publish "everything before me is done"
+            __threadfence_system();
+            *seq = seq_val;
+        }
     }
 }
 
-// w -= sum_i h[i] V_i ; partial[blk] = sum w^2 over the block
+// w -= sum_i h[i] V_i (and, with ns_scale != 0, w_phi -= h[m] * ns_scale: the gauge projection) ;
+// partial[blk] = sum w^2 over the block
 __global__ void __launch_bounds__(NT)
 k_update_norm(int n, int64_t ldv, int m, const double* __restrict__ V, const double* __restrict__ h,
-              double* __restrict__ w, double* __restrict__ partial) {
+              double* __restrict__ w, double* __restrict__ partial, double ns_scale) {
     __shared__ double sm[NT / 64];
     double acc = 0.0;
+    const double mean = ns_scale != 0.0 ? h[m] * ns_scale : 0.0;
     for (int e = blockIdx.x * NT + threadIdx.x; e < n; e += gridDim.x * NT) {
         double we = w[e];
+        if ((e & 3) == 3) we -= mean;
         for (int i = 0; i < m; ++i) we -= h[i] * V[(int64_t)i * ldv + e];
         w[e] = we;
         acc += we * we;
@@ -1315,6 +1333,10 @@ int knp_create(knp_ctx** out, const knp_mesh_desc* mesh) {
     HIPCHK(hipMemset(ctx->d_red, 0, RED_SLOTS * sizeof(double)));
     HIPCHK(hipHostMalloc((void**)&ctx->h_red, RED_SLOTS * sizeof(double), hipHostMallocMapped));
     if (hipHostGetDevicePointer((void**)&ctx->h_red_dev, ctx->h_red, 0) != hipSuccess) ctx->h_red_dev = nullptr;
+    HIPCHK(hipHostMalloc((void**)&ctx->h_seq, 64, hipHostMallocMapped));
+    *ctx->h_seq = 0;
+    if (hipHostGetDevicePointer((void**)&ctx->h_seq_dev, (void*)ctx->h_seq, 0) != hipSuccess) { ctx->h_seq_dev = nullptr; }
+    if (getenv("KNP_NO_SPIN")) ctx->h_seq_dev = nullptr;
     HIPCHK(hipMalloc((void**)&ctx->d_defl_einv, DEFL_MAX * DEFL_MAX * sizeof(double)));
     HIPCHK(hipMalloc((void**)&ctx->d_y, RED_SLOTS * sizeof(double)));
     HIPCHK(hipMalloc((void**)&ctx->d_vbj, std::max<size_t>((size_t)16 * g.n_nodes_owned, 1) * sizeof(double)));
@@ -1322,6 +1344,8 @@ int knp_create(knp_ctx** out, const knp_mesh_desc* mesh) {
     {
         const double avg_deg = g.n_nodes_owned ? (double)ctx->n_pairs / g.n_nodes_owned : 1.0;
         ctx->spmv_group = avg_deg <= 4.5 ? 4 : avg_deg <= 9.0 ? 8 : avg_deg <= 20.0 ? 16 : 32;
+        const char* ef = getenv("KNP_ASM_FULL");
+        ctx->asm_full = (ef && atoi(ef) > 0) ? 1 : 0;
         const char* e = getenv("KNP_SPMV");
         if (e && !strcmp(e, "csr")) ctx->spmv_group = 0;   // generic CSR kernel (k_spmv<L,*,1>)
         else if (e && atoi(e) > 0) ctx->spmv_group = atoi(e);
@@ -1350,6 +1374,7 @@ int knp_destroy(knp_ctx* ctx) {
     dev_free(ctx->d_cbar); dev_free(ctx->d_fmat); dev_free(ctx->d_fvec);
     dev_free(ctx->d_partial); dev_free(ctx->d_red); dev_free(ctx->d_y); dev_free(ctx->d_vbj);
     if (ctx->h_red) (void)hipHostFree(ctx->h_red);
+    if (ctx->h_seq) (void)hipHostFree((void*)ctx->h_seq);
     dev_free(ctx->d_V); dev_free(ctx->d_w); dev_free(ctx->d_t);
     for (auto& p : ctx->progs) { dev_free(p.d_code); dev_free(p.d_consts); }
     dev_free(ctx->d_prog_code); dev_free(ctx->d_prog_consts); dev_free(ctx->d_prog_len);
@@ -1450,6 +1475,7 @@ int knp_set_params(knp_ctx* ctx, double dt, double F, double C_M, double psi, in
     if (n_ions != 3 || !z || !Di || !De) { ctx->err = "n_ions must be 3 (Na, K, Cl; KNPEMIx_problem.py:980-981)"; return KNP_E_ARG; }
     if (!(dt > 0) || !(psi > 0) || F == 0.0) { ctx->err = "dt, psi must be positive and F non-zero"; return KNP_E_ARG; }
     ctx->dt = dt; ctx->F = F; ctx->C_M = C_M; ctx->psi = psi; ctx->n_ions = 3;
+    ctx->asm_dt = -1.0;   // constant blocks must be rewritten
     for (int j = 0; j < 3; ++j) {
         if (z[j] == 0.0 || !(Di[j] > 0) || !(De[j] > 0)) { ctx->err = "valence must be non-zero and diffusivities positive"; return KNP_E_ARG; }
         ctx->z[j] = z[j]; ctx->Di[j] = Di[j]; ctx->De[j] = De[j];
@@ -1544,10 +1570,21 @@ int knp_assemble_matrix(knp_ctx* ctx, const knp_fields* fields) {
     ProfScope ps(ctx, 3);
     hipLaunchKernelGGL(k_cell_means, dim3(nblocks(g.n_c)), dim3(NT), 0, ctx->stream, g.n_c, g.nv1, ctx->d_cells,
                        ctx->d_cell_side, f, ctx->d_cbar);
-    if (ctx->n_pairs)
-        hipLaunchKernelGGL((k_assemble_pairs<false>), dim3(nblocks(ctx->n_pairs)), dim3(NT), 0, ctx->stream, ctx->n_pairs,
-                           g.n_c, P, ctx->d_pair_row, ctx->d_pair_ptr, ctx->d_node_side, ctx->d_pair_M, ctx->d_pair_K,
-                           ctx->d_contrib_ptr, ctx->d_contrib_cell, ctx->d_contrib_k, ctx->d_cbar, ctx->d_rowptr, ctx->d_vals);
+    // The (k,k) and (phi,k) blocks do not depend on the previous solution (SURVEY 3.2 obs. 1): after the first
+    // assembly only the K[k_prev]-type and membrane entries are rewritten, unless KNP_ASM_FULL=1 asks for the
+    // reference's behaviour (A.zeroEntries() + full re-assembly, KNPEMIx_solver.py:110-115).
+    const bool td_only = ctx->have_A && !ctx->asm_full && ctx->asm_dt == ctx->dt;
+    if (ctx->n_pairs) {
+        if (td_only)
+            hipLaunchKernelGGL((k_assemble_pairs<false, true>), dim3(nblocks(ctx->n_pairs)), dim3(NT), 0, ctx->stream, ctx->n_pairs,
+                               g.n_c, P, ctx->d_pair_row, ctx->d_pair_ptr, ctx->d_node_side, ctx->d_pair_M, ctx->d_pair_K,
+                               ctx->d_contrib_ptr, ctx->d_contrib_cell, ctx->d_contrib_k, ctx->d_cbar, ctx->d_rowptr, ctx->d_vals);
+        else
+            hipLaunchKernelGGL((k_assemble_pairs<false, false>), dim3(nblocks(ctx->n_pairs)), dim3(NT), 0, ctx->stream, ctx->n_pairs,
+                               g.n_c, P, ctx->d_pair_row, ctx->d_pair_ptr, ctx->d_node_side, ctx->d_pair_M, ctx->d_pair_K,
+                               ctx->d_contrib_ptr, ctx->d_contrib_cell, ctx->d_contrib_k, ctx->d_cbar, ctx->d_rowptr, ctx->d_vals);
+    }
+    ctx->asm_dt = ctx->dt;
     if (g.n_g > 0) {
         if (g.dim == 2)
             hipLaunchKernelGGL((k_gamma_facets<2, true, false, 8>), dim3(nblocks((int64_t)g.n_g * 8)), dim3(NT), 0, ctx->stream, g.n_g, g.n_q, P,
@@ -1589,7 +1626,7 @@ int knp_assemble_precond(knp_ctx* ctx, const knp_fields* fields) {
     hipLaunchKernelGGL(k_cell_means, dim3(nblocks(g.n_c)), dim3(NT), 0, ctx->stream, g.n_c, g.nv1, ctx->d_cells,
                        ctx->d_cell_side, f, ctx->d_cbar);
     if (ctx->n_pairs)
-        hipLaunchKernelGGL((k_assemble_pairs<true>), dim3(nblocks(ctx->n_pairs)), dim3(NT), 0, ctx->stream, ctx->n_pairs,
+        hipLaunchKernelGGL((k_assemble_pairs<true, false>), dim3(nblocks(ctx->n_pairs)), dim3(NT), 0, ctx->stream, ctx->n_pairs,
                            g.n_c, P, ctx->d_pair_row, ctx->d_pair_ptr, ctx->d_node_side, ctx->d_pair_M, ctx->d_pair_K,
                            ctx->d_contrib_ptr, ctx->d_contrib_cell, ctx->d_contrib_k, ctx->d_cbar, ctx->d_rowptr, ctx->d_p_vals);
     if (g.n_g > 0 && ctx->n_gp)
@@ -1664,12 +1701,24 @@ static int halo_update(knp_ctx* ctx, double* x) {
 static int dot_to_slot(knp_ctx* ctx, const double* a, const double* b, int slot) {
     const int nb = ctx->n_red_blocks;
     hipLaunchKernelGGL(k_dot, dim3(nb), dim3(NT), 0, ctx->stream, ctx->n_dof_owned, a, b, ctx->d_partial);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(NT), 0, ctx->stream, nb, ctx->d_partial, ctx->d_red, slot, ctx->mirror());
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(NT), 0, ctx->stream, nb, ctx->d_partial, ctx->d_red, slot, ctx->mirror(),
+                       ctx->mirror() ? ctx->h_seq_dev : nullptr, ++ctx->seq_counter);
     return allreduce_slots(ctx, slot, 1);
 }
-static int read_slots(knp_ctx* ctx, int slot0, int count) {
-    if (ctx->allreduce || !ctx->h_red_dev)   // reduced over ranks in d_red: fetch; else the kernel already wrote the mirror
+static int read_slots(knp_ctx* ctx, int slot0, int count, int64_t wait_seq = 0) {
+    if (ctx->allreduce || !ctx->h_red_dev) {  // reduced over ranks in d_red: fetch; else the kernel already wrote the mirror
         HIPCHK(hipMemcpyAsync(ctx->h_red + slot0, ctx->d_red + slot0, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        return KNP_OK;
+    }
+    if (wait_seq > 0 && ctx->h_seq && ctx->h_seq_dev) {
+        // spin on the pinned sequence word the last reduction kernel publishes (a few microseconds instead of a
+        // full stream synchronisation); bounded: fall back to the synchronisation after ~50 ms
+        for (int64_t spin = 0; spin < (int64_t)2000000; ++spin) {
+            if (__atomic_load_n(ctx->h_seq, __ATOMIC_ACQUIRE) >= wait_seq) return KNP_OK;
+            __builtin_ia32_pause();
+        }
+    }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return KNP_OK;
 }
@@ -2127,7 +2176,7 @@ int knp_gmres_solve(knp_ctx* ctx, const double* b, double* x, double rtol, doubl
     // ||M b|| for the relative tolerance (non-zero initial guess, preconditioned norm)
     KCHK(pc_apply_proj(ctx, b, ctx->d_w, cnt));
     KCHK(dot_to_slot(ctx, ctx->d_w, ctx->d_w, 60));
-    KCHK(read_slots(ctx, 60, 1));
+    KCHK(read_slots(ctx, 60, 1, ctx->seq_counter));
     const double bnorm = std::sqrt(ctx->h_red[60]);
     if (!std::isfinite(bnorm)) { *its = 0; *rnorm = bnorm; *reason = KNP_DIVERGED_NANORINF; return KNP_OK; }
     const double ttol = std::max(rtol * bnorm, atol);
@@ -2140,7 +2189,7 @@ int knp_gmres_solve(knp_ctx* ctx, const double* b, double* x, double rtol, doubl
         KCHK(spmv_A(ctx, x, b, ctx->d_t, true));
         KCHK(pc_apply_proj(ctx, ctx->d_t, ctx->d_w, cnt));
         KCHK(dot_to_slot(ctx, ctx->d_w, ctx->d_w, 60));
-        KCHK(read_slots(ctx, 60, 1));
+        KCHK(read_slots(ctx, 60, 1, ctx->seq_counter));
         const double beta = std::sqrt(ctx->h_red[60]);
         res = beta;
         if (res0 < 0) res0 = beta;
@@ -2155,22 +2204,33 @@ int knp_gmres_solve(knp_ctx* ctx, const double* b, double* x, double rtol, doubl
         for (int j = 0; j < m; ++j) {
             double* vj = ctx->d_V + (size_t)j * ldv;
             KCHK(spmv_A(ctx, vj, nullptr, ctx->d_t, false));
-            KCHK(pc_apply_proj(ctx, ctx->d_t, ctx->d_w, cnt));
+            // The null-space removal that follows the preconditioner (KSP_RemoveNullSpace) is folded into the
+            // Gram-Schmidt pass: the basis vectors are orthogonal to ns, so h_i = V_i.(w - ns ns.w) = V_i.w, and the
+            // projection itself is one more "basis vector" in the update (same reduction, no extra all-reduce).
+            const bool ns = ctx->ns_on && cnt > 0;
+            KCHK(pc_apply_proj(ctx, ctx->d_t, ctx->d_w, ns ? 0 : cnt));
             {
                 ProfScope ps(ctx, 1);
-                for (int i0 = 0; i0 <= j; i0 += 8)
-                    hipLaunchKernelGGL((k_multi_dot<8>), dim3(nb), dim3(NT), 0, st, n, ldv, i0, j + 1, ctx->d_V, ctx->d_w, ctx->d_partial);
-                hipLaunchKernelGGL(k_reduce_partials, dim3(j + 1), dim3(NT), 0, st, nb, ctx->d_partial, ctx->d_red, 0, ctx->mirror());
-                KCHK(allreduce_slots(ctx, 0, j + 1));
-                hipLaunchKernelGGL(k_update_norm, dim3(nb), dim3(NT), 0, st, n, ldv, j + 1, ctx->d_V, ctx->d_red, ctx->d_w, ctx->d_partial);
-                hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(NT), 0, st, nb, ctx->d_partial, ctx->d_red, j + 1, ctx->mirror());
+                for (int i0 = 0; i0 <= j; i0 += 8) {
+                    if (ns && i0 == 0)
+                        hipLaunchKernelGGL((k_multi_dot<8, true>), dim3(nb), dim3(NT), 0, st, n, ldv, i0, j + 1, ctx->d_V, ctx->d_w, ctx->d_partial);
+                    else
+                        hipLaunchKernelGGL((k_multi_dot<8, false>), dim3(nb), dim3(NT), 0, st, n, ldv, i0, j + 1, ctx->d_V, ctx->d_w, ctx->d_partial);
+                }
+                const int nred = j + 1 + (ns ? 1 : 0);
+                hipLaunchKernelGGL(k_reduce_partials, dim3(nred), dim3(NT), 0, st, nb, ctx->d_partial, ctx->d_red, 0, ctx->mirror());
+                KCHK(allreduce_slots(ctx, 0, nred));
+                hipLaunchKernelGGL(k_update_norm, dim3(nb), dim3(NT), 0, st, n, ldv, j + 1, ctx->d_V, ctx->d_red, ctx->d_w, ctx->d_partial,
+                                   ns ? 1.0 / (double)cnt : 0.0);
+                hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(NT), 0, st, nb, ctx->d_partial, ctx->d_red, j + 1, ctx->mirror(),
+                                   ctx->mirror() ? ctx->h_seq_dev : nullptr, ++ctx->seq_counter);
                 KCHK(allreduce_slots(ctx, j + 1, 1));
                 if (j + 1 < m + 1)
                     hipLaunchKernelGGL(k_scale_rsqrt, dim3(std::min(nblocks(n), 2048)), dim3(NT), 0, st, n, ctx->d_w, ctx->d_red + j + 1,
                                        ctx->d_V + (size_t)(j + 1) * ldv);
                 HIPCHK(hipGetLastError());
             }
-            KCHK(read_slots(ctx, 0, j + 2));
+            KCHK(read_slots(ctx, 0, j + 2, ctx->seq_counter));
             const double hn = std::sqrt(std::max(ctx->h_red[j + 1], 0.0));
             for (int i = 0; i <= j; ++i) Hx(i, j) = ctx->h_red[i];
             Hx(j + 1, j) = hn;
