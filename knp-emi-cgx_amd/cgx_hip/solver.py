@@ -80,7 +80,7 @@ class SolverKNPEMI:
     amg_pre = 1
     amg_post = 1
     amg_coarse_size = 2500
-    amg_replicate_below = 40000
+    amg_replicate_below = 300000
 
     def __init__(self, problem: ProblemKNPEMI, solver_config: dict):
         self.problem = problem
