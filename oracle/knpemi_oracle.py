@@ -355,6 +355,7 @@ class OracleKNPEMI:
         self.cnode = node                                           # (n_c, d+1)
         self.rowsA = np.repeat(node[:, :, None], nv1, axis=2)       # node of row a
         self.colsA = np.repeat(node[:, None, :], nv1, axis=1)       # node of col b
+        self.lamq = self.qp                                         # (n_q, d) facet basis table
         # stimulus area (KNPEMIx_ionic_model.py:591-601)
         stim = np.isin(self.gamma_tag, self.stimulus_tags)
         self.stim_facet = stim

@@ -81,3 +81,36 @@ def run_oracle(N=32, steps=10, kind="square", models="ci", solver="lu_gauge"):
     o = make_oracle(N, kind, models)
     o.run(steps, solver=solver)
     return o
+
+
+def two_cell_mesh(N=16):
+    """Unit square with two inclusions: a 'neuron' (tag 2) and a 'glial cell' (tag 3) in extracellular space (tag 1);
+    membrane facets carry the tag of their cell (the convention of the reference's tissue configs:
+    'membrane tag = intra tag', mixed_dim_problem.py:403-407)."""
+    import numpy as np
+    from cgx_hip import mesh as meshmod
+    coords, cells = meshmod.create_unit_square(N)
+    cx = coords[cells].mean(axis=1)
+    allv = lambda lo, hi: ((coords[cells] >= lo) & (coords[cells] <= hi)).all(axis=(1, 2))
+    tags = np.full(cells.shape[0], 1, dtype=np.int32)
+    box = lambda x0, x1, y0, y1: ((coords[cells][:, :, 0] >= x0) & (coords[cells][:, :, 0] <= x1) &
+                                  (coords[cells][:, :, 1] >= y0) & (coords[cells][:, :, 1] <= y1)).all(axis=1)
+    tags[box(0.125, 0.4375, 0.25, 0.75)] = 2
+    tags[box(0.5625, 0.875, 0.25, 0.75)] = 3
+    gamma, _, fverts = meshmod.gamma_integration_entities(cells, tags, (2, 3), (1,))
+    ftags = tags[gamma[:, 0]]
+    return coords, cells, tags, fverts, ftags
+
+
+def two_cell_config(path, steps=2, rtol=1e-11, pc="hypre"):
+    import copy
+    cfg = copy.deepcopy(CI_BASE)
+    cfg.update({"time_steps": steps, "cell_tag_file": path, "facet_tag_file": path, "input_dir": "",
+                "ics_tags": [2, 3], "ecs_tags": [1], "membrane_tags": [2, 3], "glia_tags": [3], "stimulus_tags": [2],
+                "stimulus_region": {"direction": "y", "range": [0.3, 0.6]},
+                "initial_conditions": {"phi_m_n": -0.070, "phi_m_g": -0.082, "Na_i_n": 12, "Na_i_g": 15, "Na_e": 140,
+                                       "K_i_n": 130, "K_i_g": 100, "K_e": 4, "Cl_i_n": 5, "Cl_i_g": 6, "Cl_e": 125,
+                                       "n": 0.276, "m": 0.0379, "h": 0.688}})
+    cfg["solver"]["ksp_settings"]["ksp_rtol"] = rtol
+    cfg["solver"]["ksp_settings"]["pc_type"] = pc
+    return cfg

@@ -1,3 +1,4 @@
+"""Developer tool (not part of the product or the tests); run on a GPU box from the repo root."""
 import sys; sys.path.insert(0,'tests'); import conftest
 import numpy as np
 from parity_utils import *
