@@ -14,11 +14,13 @@ Pinning status
   (``tests/KNPEMI/electric_potential_norms_iterative_solver.py:58-59`` to the
   reference's tolerance 1e-7 rel., and ``..._direct_solver.py:55-56`` modulo the
   single gauge constant MUMPS picks).
-* 3D (unit cube): "parity unpinned" -- the reference holds no 3D result for this
-  path.  The 3D facet rule here (collapsed Gauss-Jacobi 6x6, exact to degree 11)
-  differs from basix's Xiao-Gimbutas 25-point degree-10 rule (third-party,
-  tables not in /root/reference); both integrate the smooth Gamma integrands to
-  round-off for P1 data.
+* 3D (unit cube): PINNED through the manufactured-solution path.  ``oracle/mms_oracle.py``
+  restates the reference's MMS set-up on top of this file and reproduces the reference's
+  recorded L2 errors (src/CGx/utils/errors.py:8-28) to 5 significant digits for the potentials on
+  N = 8, 16, 32 (3D) and N = 8 ... 128 (2D) -- ``tests/test_oracle_mms.py``.  The 3D facet rule
+  here (collapsed Gauss-Jacobi 6x6, exact to degree 11) differs from basix's Xiao-Gimbutas
+  25-point degree-10 rule (third-party, tables not in /root/reference); both integrate the smooth
+  Gamma integrands far below those 5 digits.
 
 Reference lines restated (all relative to /root/reference):
   meshes/markers   src/CGx/utils/generate_square_mesh.py:28-42, src/CGx/utils/misc.py:99-195,256-398
