@@ -168,6 +168,10 @@ int knp_set_params(knp_ctx* ctx, double dt, double F, double C_M, double psi, in
 int knp_set_program(knp_ctx* ctx, int32_t prog_id, int32_t n_instr, const int32_t* code /* host [n_instr*4] */,
                     int32_t n_consts, const double* consts /* host */);
 int knp_set_program_constants(knp_ctx* ctx, int32_t prog_id, int32_t n_consts, const double* consts);
+/* Dirichlet conditions (reference: dfx.fem.dirichletbc + bcs= of assemble_*_block, KNPEMIx_problem.py:106-134,
+ * KNPEMIx_solver.py:114-116): rows of the listed owned DoFs become identity rows in A and P at every assembly;
+ * the caller sets b[dof] = g.  (DOLFINx also eliminates the columns; same solution.) n = 0 clears. host array. */
+int knp_set_dirichlet(knp_ctx* ctx, int32_t n, const int32_t* dofs);
 /* volumetric source terms dt*f (KNPEMIx_problem.py:613-614); NULL pointers mean zero. nodal, device. */
 int knp_set_sources(knp_ctx* ctx, const double* const* f_i, const double* const* f_e);
 

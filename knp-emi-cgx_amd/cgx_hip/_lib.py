@@ -70,6 +70,7 @@ SIGNATURES = {
     "knp_set_params": (C.c_int, [vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, f64p, f64p, f64p]),
     "knp_set_program": (C.c_int, [vp, C.c_int32, C.c_int32, i32p, C.c_int32, f64p]),
     "knp_set_program_constants": (C.c_int, [vp, C.c_int32, C.c_int32, f64p]),
+    "knp_set_dirichlet": (C.c_int, [vp, C.c_int32, i32p]),
     "knp_set_sources": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp)]),
     "knp_assemble_matrix": (C.c_int, [vp, C.POINTER(Fields)]),
     "knp_assemble_rhs": (C.c_int, [vp, C.POINTER(Fields), vp]),

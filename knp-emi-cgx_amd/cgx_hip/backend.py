@@ -106,6 +106,28 @@ class Backend:
         if getattr(problem, "programs", None):
             self.upload_programs()
         self.setup_deflation()
+        self.setup_dirichlet()
+
+    def setup_dirichlet(self):
+        """Dirichlet rows (MMS runs): extracellular unknowns at the exterior-boundary vertices."""
+        p = self.p
+        self.bc_dofs = None
+        if not getattr(p, "bcs", None):
+            return
+        dofs, vals = [], []
+        for side, f, verts, values in p.bcs:
+            nodes = (self.node_e if side == "extra" else self.node_i)[verts]
+            ok = (nodes >= 0) & (nodes < self.n_nodes_owned)
+            dofs.append(4 * nodes[ok] + f)
+            vals.append(np.asarray(values)[ok])
+        dofs = np.ascontiguousarray(np.concatenate(dofs), dtype=np.int32)
+        self.bc_dofs = torch.as_tensor(dofs.astype(np.int64), device=self.device)
+        self.bc_vals = torch.as_tensor(np.concatenate(vals), dtype=torch.float64, device=self.device)
+        self.check(self.lib.knp_set_dirichlet(self.ctx, len(dofs), _i32(dofs)))
+
+    def apply_dirichlet_rhs(self):
+        if self.bc_dofs is not None:
+            self.b.index_copy_(0, self.bc_dofs, self.bc_vals)
 
     def setup_deflation(self):
         """Multi-GPU only: coarse correction for the floating-potential modes cut by the partition

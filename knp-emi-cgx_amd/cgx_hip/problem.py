@@ -163,9 +163,18 @@ class MixedDimensionalProblem(ABC):
         if "dirichlet_bcs" in config:
             self.dirichlet_bcs = bool(config["dirichlet_bcs"])
         if "MMS_test" in config:
-            raise NotImplementedError("MMS_test configs are not supported yet by the MI355X-native path (SURVEY 8f-1).")
-        if self.dirichlet_bcs:
-            raise NotImplementedError("dirichlet_bcs: True is not supported yet by the MI355X-native path; "
+            self.MMS_test = True
+            self.dirichlet_bcs = True
+            try:
+                self.N_mesh = int(config["MMS_test"]["N_mesh"])
+            except Exception:
+                raise RuntimeError('For MMS test, provide number of mesh cells "N_mesh" in input file.')
+            try:
+                self.dim = int(config["MMS_test"]["dim"])
+            except Exception:
+                raise RuntimeError('For MMS test, provide dimension "dim" in input file.')
+        elif self.dirichlet_bcs:
+            raise NotImplementedError("dirichlet_bcs without MMS_test is not supported yet by the MI355X-native path; "
                                       "the hot path implements the pure-Neumann case (null-space gauge).")
         self.source_terms = config.get("source_terms", None)
         if self.source_terms is not None:
@@ -222,6 +231,9 @@ class MixedDimensionalProblem(ABC):
 
         if "initial_conditions" in config:
             self.initial_conditions = config["initial_conditions"]
+            self.find_initial_conditions = False
+        elif self.MMS_test:
+            self.initial_conditions = {}
             self.find_initial_conditions = False
         else:
             raise NotImplementedError("Configs without 'initial_conditions' need the reference's 0-D ODE pre-processor "
@@ -287,6 +299,26 @@ class MixedDimensionalProblem(ABC):
         self.print("Setting up mesh ...")
         if self._local_mesh_override is not None:
             lm = self._local_mesh_override
+            self.mesh_description = lm.description
+        elif self.MMS_test:
+            # mixed_dim_problem.py:683-700: unit square / cube, one membrane tag per side of the inner box, boundary tag 8
+            if self.comm.size != 1:
+                raise NotImplementedError("MMS runs are single-GPU verification runs.")
+            gen = meshmod.create_unit_square if self.dim == 2 else meshmod.create_unit_cube
+            coords, cells = gen(self.N_mesh)
+            cell_tags = meshmod.mark_subdomains_box(coords, cells)
+            self.gamma_tags = (1, 2, 3, 4) if self.dim == 2 else (1, 2, 3, 4, 5, 6)
+            gamma, _, gverts = meshmod.gamma_integration_entities(cells, cell_tags, self.intra_tags, self.extra_tag, None)
+            cen = coords[gverts].mean(axis=1)
+            gtags = np.zeros(len(gamma), dtype=np.int32)
+            # misc.py:196-254 (square: LEFT 1, RIGHT 2, BOTTOM 3, TOP 4) / :400-503 (cube: LEFT, RIGHT, FRONT, BACK, BOTTOM, TOP)
+            sides = [(0, 0.25, 1), (0, 0.75, 2), (1, 0.25, 3), (1, 0.75, 4)] if self.dim == 2 else \
+                    [(0, 0.25, 1), (0, 0.75, 2), (1, 0.25, 3), (1, 0.75, 4), (2, 0.25, 5), (2, 0.75, 6)]
+            for ax, val, tag in sides:
+                gtags[np.isclose(cen[:, ax], val)] = tag
+            assert gtags.min() >= 1, "MMS meshes need N_mesh divisible by 4"
+            lm = partition_mesh(coords, cells, cell_tags, gamma, gtags, 1, 0)
+            lm.description = f"MMS unit {'square' if self.dim == 2 else 'cube'} N={self.N_mesh}"
             self.mesh_description = lm.description
         else:
             coords, cells, cell_tags, facet_tags, desc = meshmod.load_mesh(
@@ -380,7 +412,33 @@ def _aslist(v):
 class ProblemKNPEMI(MixedDimensionalProblem):
 
     def init(self):
-        pass
+        if self.MMS_test:
+            self.setup_MMS_params()
+
+    # ---- MMS parameters (KNPEMIx_problem.py:746-805)
+    def setup_MMS_params(self):
+        from .mms import ExactSolutionsKNPEMI
+        self.print("Setting up MMS parameters ...")
+        assert np.allclose([self.C_M.value, self.R.value, self.F.value, self.psi.value], [1.0] * 4)
+        self.M = ExactSolutionsKNPEMI(self.mesh, self.t)
+        self.exact_sols, self.src_terms = self.M.get_mms_terms()
+        self.phi_i_init = self.exact_sols["phi_i_init"]
+        self.phi_e_init = self.exact_sols["phi_e_init"]
+        self.phi_m_init = self.phi_i_init - self.phi_e_init
+        m = self.mesh
+        self.ion_list = []
+        for name, z in (("Na", 1.0), ("K", 1.0), ("Cl", -1.0)):
+            self.ion_list.append({"name": name, "Di": Constant(m, 1.0), "De": Constant(m, 1.0), "z": Constant(m, z),
+                                  "ki_init": self.exact_sols[f"{name}_i"], "ke_init": self.exact_sols[f"{name}_e"],
+                                  "f_k_i": self.src_terms[f"f_{name}_i"], "f_k_e": self.src_terms[f"f_{name}_e"],
+                                  "J_k_e": self.src_terms[f"J_{name}_e"], "f_I_m": self.src_terms[f"f_phi_{name}"],
+                                  "f_i": Constant(m, 0.0), "f_e": Constant(m, 0.0),
+                                  "g_leak": Constant(m, 0.0), "g_leak_g": Constant(m, 0.0)})
+        self.Na, self.K, self.Cl = self.ion_list
+        self.N_ions = len(self.ion_list)
+
+    def _exact_nodal(self, expr):
+        return self.M.evaluate(expr, self.mesh.geometry.x, float(self.t.value))
 
     # ---- spaces & restrictions (KNPEMIx_problem.py:28-94)
     def setup_spaces(self):
@@ -413,12 +471,36 @@ class ProblemKNPEMI(MixedDimensionalProblem):
     def setup_boundary_conditions(self):
         self.print("Setting up boundary conditions ...")
         self.bcs = []          # pure Neumann (reference default, KNPEMIx_problem.py:104,198)
+        if self.MMS_test:
+            # KNPEMIx_problem.py:109-134: extracellular concentrations and phi_e on the whole exterior boundary,
+            # values interpolated from the exact solution when the BCs are created (t = 0)
+            x = self.mesh.geometry.x
+            on_bdry = np.any(np.isclose(x, 0.0) | np.isclose(x, 1.0), axis=1)
+            self.bc_vertices = np.nonzero(on_bdry)[0].astype(np.int32)
+            xb = x[self.bc_vertices]
+            self.bc_values = [self.M.evaluate(self.exact_sols[f"{ion['name']}_e"], xb, float(self.t.value)) for ion in self.ion_list]
+            self.bc_values.append(self.M.evaluate(self.exact_sols["phi_e"], xb, float(self.t.value)))
+            self.bcs = [("extra", f, self.bc_vertices, self.bc_values[f]) for f in range(self.num_variables)]
 
     def setup_source_terms(self):
         raise NotImplementedError
 
     # ---- initial conditions (KNPEMIx_problem.py:326-353, 386-452)
     def set_initial_conditions(self):
+        if self.MMS_test:
+            # KNPEMIx_problem.py:363-385, 417-431: interpolate the exact solution at t = 0
+            self.print("Setting initial conditions for MMS test ...")
+            dev = self.mesh.device
+            as_t = lambda a: torch.as_tensor(np.array(a, dtype=np.float64, copy=True), device=dev)
+            self.phi_m_prev = Function(self.V, "phi_m")
+            self.phi_m_prev.x.array[:] = as_t(self._exact_nodal(self.phi_m_init))
+            self.wh[0][self.N_ions].x.array[:] = as_t(self._exact_nodal(self.phi_i_init))
+            self.wh[1][self.N_ions].x.array[:] = as_t(self._exact_nodal(self.phi_e_init))
+            for idx, ion in enumerate(self.ion_list):
+                self.wh[0][idx].x.array[:] = as_t(self._exact_nodal(ion["ki_init"]))
+                self.wh[1][idx].x.array[:] = as_t(self._exact_nodal(ion["ke_init"]))
+            self.print("Initial conditions set.")
+            return
         self.print("Setting initial conditions from input file ...")
         ic = self.initial_conditions
         if not self.glia_flag:
@@ -524,7 +606,15 @@ class ProblemKNPEMI(MixedDimensionalProblem):
             self.print(f"Total {name} concentration: {v:.2e} mol")
 
     def print_errors(self):
-        raise NotImplementedError("MMS path not available (SURVEY 8f-1).")
+        """L2 errors against the exact solution at the current time (KNPEMIx_problem.py:845-907)."""
+        if not hasattr(self, "_mms_asm"):
+            from .mms import MMSAssembler
+            self._mms_asm = MMSAssembler(self)
+        e = self._mms_asm.l2_errors()          # [Na_i, Na_e, K_i, K_e, Cl_i, Cl_e, phi_i, phi_e]
+        self.print("#-------------- ERRORS --------------#")
+        for nm, v in zip(("Na_i ", "Na_e ", "K_i  ", "K_e  ", "Cl_i ", "Cl_e ", "phi_i", "phi_e"), e):
+            self.print(f"L2 {nm} error:", v)
+        self.errors = e
 
     # ---- constants (KNPEMIx_problem.py:909-981)
     def setup_constants(self):

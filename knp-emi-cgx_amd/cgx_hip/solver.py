@@ -134,8 +134,18 @@ class SolverKNPEMI:
     def assemble(self):
         self.print("Assembling linear system ...")
         be = self.backend
+        p = self.problem
         be.assemble_matrix()
         be.assemble_rhs()
+        if p.MMS_test:
+            # extra terms of L for the manufactured solution (KNPEMIx_problem.py:616-651): host integrals of the
+            # analytic sources, added to the device vector; then the Dirichlet values (bcs= of assemble_vector_block)
+            if not hasattr(p, "_mms_asm"):
+                from .mms import MMSAssembler
+                p._mms_asm = MMSAssembler(p)
+            extra = p._mms_asm.rhs_vector(be.node_i, be.node_e, be.n_dof_local)
+            be.b += torch.as_tensor(extra, dtype=torch.float64, device=be.device)
+        be.apply_dirichlet_rhs()
 
     # ---- reference :118-135
     def assemble_preconditioner(self):
@@ -214,8 +224,9 @@ class SolverKNPEMI:
             self._pc_kind = {"hypre": _lib.PC_AMG, "amg": _lib.PC_AMG, "btcc": _lib.PC_AMG_BT, "bjacobi": _lib.PC_VBJACOBI,
                              "vbjacobi": _lib.PC_VBJACOBI, "none": _lib.PC_NONE}[self.pc_type]
             self._rtol = self.ksp_rtol
-        # initial conditions as initial guess (reference :177-209)
-        for idx, ion in enumerate(p.ion_list):
+        # initial conditions as initial guess (reference :177-209).  In MMS runs the initial data are fields
+        # (already interpolated by set_initial_conditions); the reference would need its direct solver there.
+        for idx, ion in enumerate(p.ion_list if not p.MMS_test else []):
             if not p.glia_flag:
                 p.wh[0][idx].x.array[:] = ion["ki_init"].value
                 p.wh[1][idx].x.array[:] = ion["ke_init"].value
@@ -223,7 +234,9 @@ class SolverKNPEMI:
                 p.wh[0][idx].x.array[p.neuron_dofs] = ion["ki_init_n"].value
                 p.wh[0][idx].x.array[p.glia_dofs] = ion["ki_init_g"].value
                 p.wh[1][idx].x.array[:] = ion["ke_init"].value
-        if not p.glia_flag:
+        if p.MMS_test:
+            pass
+        elif not p.glia_flag:
             p.wh[0][p.N_ions].x.array[:] = p.phi_m_init.value
             p.wh[1][p.N_ions].x.array[:] = 0.0
         else:
@@ -327,6 +340,8 @@ class SolverKNPEMI:
                 raise RuntimeError(f"GMRES did not converge at step {i}: {_lib.REASONS.get(reason, reason)}")
 
             be.unpack()                                # x -> wh, phi_m_prev = phi_i - phi_e (reference :452-468)
+            if p.MMS_test:
+                p.print_errors()                       # reference :500-501
 
             if i == self.time_steps:
                 self.setup_time = setup_timer

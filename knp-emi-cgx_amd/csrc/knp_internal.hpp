@@ -159,6 +159,9 @@ struct knp_ctx {
     int64_t seq_counter = 0;
     int asm_full = 0;                // KNP_ASM_FULL=1: rewrite the time-invariant blocks at every assembly
     double asm_dt = -1.0;
+    // Dirichlet rows
+    int n_bc = 0;
+    int32_t* d_bc_dofs = nullptr;
     // deflation
     int defl_m = 0;
     int32_t* d_defl_mode = nullptr;

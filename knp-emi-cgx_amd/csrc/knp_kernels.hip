@@ -916,6 +916,33 @@ k_defl_add(int n_nodes, int m, const int32_t* __restrict__ node_mode, const doub
 }
 
 // ------------------------------------------------------------------------------------------
+// Dirichlet conditions (MMS path; KNPEMIx_problem.py:106-134): the row of a constrained DoF becomes the
+// identity row (the right-hand side entry is set by the caller).  DOLFINx additionally zeroes the column and
+// lifts the right-hand side; the solution is the same.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(NT)
+k_dirichlet_rows_A(int n_bc, const int32_t* __restrict__ bc_dofs, const int32_t* __restrict__ rowptr,
+                   const int32_t* __restrict__ colind, double* __restrict__ vals) {
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= n_bc) return;
+    const int row = bc_dofs[i];
+    bool done = false;
+    for (int k = rowptr[row]; k < rowptr[row + 1]; ++k) {
+        const bool diag = !done && colind[k] == row;
+        vals[k] = diag ? 1.0 : 0.0;
+        done = done || diag;
+    }
+}
+__global__ void __launch_bounds__(NT)
+k_dirichlet_rows_P(int n_bc, const int32_t* __restrict__ bc_dofs, const int32_t* __restrict__ pair_ptr,
+                   const int32_t* __restrict__ pair_col, double* __restrict__ pv) {
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= n_bc) return;
+    const int row = bc_dofs[i], node = row >> 2, f = row & 3;
+    for (int p = pair_ptr[node]; p < pair_ptr[node + 1]; ++p) pv[(size_t)4 * p + f] = (pair_col[p] == node) ? 1.0 : 0.0;
+}
+
+// ------------------------------------------------------------------------------------------
 // K7: vertex-block Jacobi built from A.  blk[n*16 + {0..2: d_j, 3..5: u_j, 6..8: v_j, 9: s,
 //                                         10..12: ux_j (k rows -> other side's phi), 13: sx}]
 // ------------------------------------------------------------------------------------------
@@ -1389,7 +1416,7 @@ int knp_destroy(knp_ctx* ctx) {
         dev_free(H.cinv);
     }
     dev_free(ctx->d_ML); dev_free(ctx->d_cc); dev_free(ctx->d_t2); dev_free(ctx->d_w2);
-    dev_free(ctx->d_defl_mode); dev_free(ctx->d_defl_einv);
+    dev_free(ctx->d_defl_mode); dev_free(ctx->d_defl_einv); dev_free(ctx->d_bc_dofs);
     delete ctx;
     return KNP_OK;
 }
@@ -1541,6 +1568,22 @@ static int sync_program_table(knp_ctx* ctx) {
     return KNP_OK;
 }
 
+int knp_set_dirichlet(knp_ctx* ctx, int32_t n, const int32_t* dofs) {
+    CHECK_CTX(ctx);
+    if (n < 0 || (n > 0 && !dofs)) { ctx->err = "bad Dirichlet arguments"; return KNP_E_ARG; }
+    for (int i = 0; i < n; ++i)
+        if (dofs[i] < 0 || dofs[i] >= ctx->n_dof_owned) { ctx->err = "Dirichlet dof out of range (owned dofs only)"; return KNP_E_ARG; }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    dev_free(ctx->d_bc_dofs);
+    ctx->n_bc = 0;
+    if (n > 0) {
+        KCHK(dev_upload_raw(ctx, &ctx->d_bc_dofs, dofs, (size_t)n));
+        ctx->n_bc = n;
+    }
+    ctx->asm_dt = -1.0;   // constant blocks of the touched rows must be rewritten if the set changes
+    return KNP_OK;
+}
+
 int knp_set_sources(knp_ctx* ctx, const double* const* fi, const double* const* fe) {
     CHECK_CTX(ctx);
     ctx->have_sources = false;
@@ -1602,6 +1645,9 @@ int knp_assemble_matrix(knp_ctx* ctx, const knp_fields* fields) {
                                ctx->d_gcptr, ctx->d_gc_facet, ctx->d_gc_lab, ctx->d_fmeas, ctx->d_fmat, ctx->d_pair_ptr,
                                ctx->d_rowptr, ctx->d_vals);
     }
+    if (ctx->n_bc > 0)
+        hipLaunchKernelGGL(k_dirichlet_rows_A, dim3(nblocks(ctx->n_bc)), dim3(NT), 0, ctx->stream, ctx->n_bc, ctx->d_bc_dofs, ctx->d_rowptr,
+                           ctx->d_colind, ctx->d_vals);
     hipLaunchKernelGGL(k_schur_diag, dim3(nblocks(g.n_nodes_owned)), dim3(NT), 0, ctx->stream, g.n_nodes_owned, ctx->psi, ctx->z[0], ctx->z[1],
                        ctx->z[2], ctx->d_node_vertex, ctx->d_node_side, f, ctx->d_ML, ctx->d_cc);
     ctx->have_cc = true;
@@ -1634,6 +1680,9 @@ int knp_assemble_precond(knp_ctx* ctx, const knp_fields* fields) {
                            ctx->d_grow, ctx->d_gptr, ctx->d_gv_node_i, ctx->d_gv_node_e, ctx->d_gq_i, ctx->d_gq_e,
                            ctx->d_gcptr, ctx->d_gc_facet, ctx->d_gc_lab, ctx->d_fmeas, ctx->d_fmat, ctx->d_pair_ptr,
                            ctx->d_rowptr, ctx->d_p_vals);
+    if (ctx->n_bc > 0)
+        hipLaunchKernelGGL(k_dirichlet_rows_P, dim3(nblocks(ctx->n_bc)), dim3(NT), 0, ctx->stream, ctx->n_bc, ctx->d_bc_dofs, ctx->d_pair_ptr,
+                           ctx->d_pair_col, ctx->d_p_vals);
     HIPCHK(hipGetLastError());
     ctx->have_P = true;
     return KNP_OK;

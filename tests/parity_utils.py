@@ -114,3 +114,15 @@ def two_cell_config(path, steps=2, rtol=1e-11, pc="hypre"):
     cfg["solver"]["ksp_settings"]["ksp_rtol"] = rtol
     cfg["solver"]["ksp_settings"]["pc_type"] = pc
     return cfg
+
+
+def mms_config(dim=2, N=8, dt=1e-5, steps=1, rtol=1e-12):
+    """reference src/CGx/KNPEMI/configs/mms_config.yaml (+ the 'solver' section it lacks)"""
+    return {"problem_type": "KNP-EMI", "quiet": True, "dt": dt, "time_steps": steps,
+            "physical_constants": {"T": 1.0, "F": 1.0, "R": 1.0}, "C_M": 1.0,
+            "cell_tag_file": f"{'square' if dim == 2 else 'cube'}{N}.xdmf", "facet_tag_file": f"{'square' if dim == 2 else 'cube'}{N}_facets.xdmf",
+            "ics_tags": [1], "ecs_tags": [2], "boundary_tags": [8], "membrane_tags": [1, 2, 3, 4], "stimulus_tags": [],
+            "MMS_test": {"N_mesh": N, "dim": dim},
+            "solver": {"direct": False,
+                       "ksp_settings": {"ksp_rtol": rtol, "ksp_type": "gmres", "pc_type": "hypre", "ksp_max_it": 2000},
+                       "output": {"save_xdmf": False, "save_cpoints": False, "save_pngs": False, "save_dat": False}}}

@@ -1,0 +1,44 @@
+"""MMS verification path on the GPU (MMS_test configs): Dirichlet rows in the library, analytic sources from the
+host layer; checked against the oracle's MMS run and against the reference's recorded errors
+(src/CGx/utils/errors.py:8-28)."""
+import numpy as np
+import pytest
+
+from parity_utils import mms_config
+
+pytestmark = pytest.mark.gpu
+
+
+def _native_errors(dim, N):
+    from CGx.KNPEMI.KNPEMIx_ionic_model import PassiveModel
+    from CGx.KNPEMI.KNPEMIx_problem import ProblemKNPEMI
+    from CGx.KNPEMI.KNPEMIx_solver import SolverKNPEMI
+    p = ProblemKNPEMI(mms_config(dim, N))
+    p.set_initial_conditions()
+    p.init_ionic_models([PassiveModel(p)])
+    p.setup_variational_form()
+    p.solver_config["view_ksp"] = False
+    s = SolverKNPEMI(p, solver_config=p.solver_config)
+    s.solve()
+    assert all(r > 0 for r in s.reasons), s.reasons
+    return np.array(p.errors), s
+
+
+@pytest.mark.parametrize("dim,N,level", [(2, 8, 0), (2, 16, 1), (2, 32, 2), (3, 8, 0)])
+def test_mms_errors_match_oracle_and_reference_record(dim, N, level):
+    import mms_oracle as M
+    e, s = _native_errors(dim, N)
+    eo = M.run_mms(dim, N)
+    assert np.allclose(e, eo, rtol=1e-6), (e, eo)
+    rec = (M.RECORDED_2D if dim == 2 else M.RECORDED_3D)[level]
+    assert np.allclose(e[6:], rec[6:], rtol=2e-5)          # potentials: the reference's recorded values
+    assert np.allclose(e[:6], rec[:6], rtol=5e-3)
+
+
+def test_mms_second_order_on_gpu():
+    e8, _ = _native_errors(2, 8)
+    e16, _ = _native_errors(2, 16)
+    e32, _ = _native_errors(2, 32)
+    r = np.log2(e16 / e32)
+    assert np.all(r > 1.9) and np.all(r < 2.1)
+    assert np.all(np.log2(e8 / e16) > 1.8)
