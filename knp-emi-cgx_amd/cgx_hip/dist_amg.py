@@ -28,72 +28,79 @@ from . import amg
 
 
 class LevelHalo:
-    """Forward / reverse halo of one level.  Local vector layout: [owned (n_own) | ghost (n_ghost)]."""
+    """Forward / reverse halo of one level.  Local vector layout: [owned (n_own) | ghost (n_ghost)].
+    One packed send buffer and ONE ``all_to_all_single`` per exchange (three torch calls per halo)."""
 
     def __init__(self, comm, n_own, ghost_gid, ghost_owner, own_gid_start, device):
         self.comm = comm
         self.n_own = int(n_own)
         self.n_loc = int(n_own + len(ghost_gid))
         self.device = device
-        self.send_idx, self.recv_idx = {}, {}
+        recv_idx, send_idx = {}, {}
         req = {}
         for o in np.unique(ghost_owner) if len(ghost_owner) else []:
             sel = np.nonzero(ghost_owner == o)[0]
             req[int(o)] = ghost_gid[sel]
-            self.recv_idx[int(o)] = torch.as_tensor(self.n_own + sel, dtype=torch.long, device=device)
+            recv_idx[int(o)] = self.n_own + sel
         gathered = comm.all_gather_object(req)
         for r, rq in enumerate(gathered):
             if r == comm.rank or comm.rank not in rq:
                 continue
             loc = np.asarray(rq[comm.rank], dtype=np.int64) - own_gid_start
             assert (loc >= 0).all() and (loc < self.n_own).all(), "halo request for a row this rank does not own"
-            self.send_idx[r] = torch.as_tensor(loc, dtype=torch.long, device=device)
-        self.peers = sorted(set(self.send_idx) | set(self.recv_idx))
-        self._sb = {r: torch.empty(len(ix), dtype=torch.float64, device=device) for r, ix in self.send_idx.items()}
-        self._rb = {r: torch.empty(len(ix), dtype=torch.float64, device=device) for r, ix in self.recv_idx.items()}
-        self.staged = comm.backend != "nccl" and torch.device(device).type == "cuda"
+            send_idx[r] = loc
+        self._finish(send_idx, recv_idx)
 
-    def _xfer(self, send, recv):
-        """send: {peer: tensor to send}, recv: {peer: tensor to fill}"""
+    def _finish(self, send_idx, recv_idx):
+        comm, device = self.comm, self.device
+        self.send_idx = {r: torch.as_tensor(np.asarray(v, dtype=np.int64), device=device) for r, v in send_idx.items()}
+        self.recv_idx = {r: torch.as_tensor(np.asarray(v, dtype=np.int64), device=device) for r, v in recv_idx.items()}
+        self.peers = sorted(set(send_idx) | set(recv_idx))
+        size = max(comm.size, 1)
+        self.in_splits = [len(send_idx.get(r, ())) for r in range(size)]       # what this rank sends to r
+        self.out_splits = [len(recv_idx.get(r, ())) for r in range(size)]      # what it receives from r
+        cat = lambda d: np.concatenate([np.asarray(d[r], dtype=np.int64) for r in sorted(d)]) if d else np.zeros(0, np.int64)
+        self.send_all = torch.as_tensor(cat(send_idx), device=device)
+        self.recv_all = torch.as_tensor(cat(recv_idx), device=device)
+        self._sb = torch.empty(len(self.send_all), dtype=torch.float64, device=device)
+        self._rb = torch.empty(len(self.recv_all), dtype=torch.float64, device=device)
+        self.staged = comm.backend != "nccl" and torch.device(device).type == "cuda"
         if self.staged:
-            hs = {r: t.cpu() for r, t in send.items()}
-            hr = {r: torch.empty(t.shape, dtype=t.dtype) for r, t in recv.items()}
+            self._sh = torch.empty(len(self.send_all), dtype=torch.float64).pin_memory()
+            self._rh = torch.empty(len(self.recv_all), dtype=torch.float64).pin_memory()
+
+    def _a2a(self, out, inp, out_splits, in_splits, out_host=None, in_host=None):
+        if self.staged:
+            in_host[:len(inp)].copy_(inp)
+            torch.cuda.current_stream().synchronize()
+            dist.all_to_all_single(out_host, in_host, out_splits, in_splits)
+            out.copy_(out_host)
         else:
-            hs, hr = send, recv
-        ops = []
-        for r in self.peers:
-            if r in hr:
-                ops.append(dist.P2POp(dist.irecv, hr[r], r))
-            if r in hs:
-                ops.append(dist.P2POp(dist.isend, hs[r], r))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-        if self.staged:
-            for r, t in recv.items():
-                t.copy_(hr[r])
+            dist.all_to_all_single(out, inp, out_splits, in_splits)
 
     def forward(self, x):
         """ghost entries of x <- owner values"""
         if not self.peers:
             return
-        for r, ix in self.send_idx.items():
-            torch.index_select(x, 0, ix, out=self._sb[r])
-        self._xfer(self._sb, self._rb)
-        for r, ix in self.recv_idx.items():
-            x.index_copy_(0, ix, self._rb[r])
+        torch.index_select(x, 0, self.send_all, out=self._sb)
+        if self.staged:
+            self._a2a(self._rb, self._sb, self.out_splits, self.in_splits, self._rh, self._sh)
+        else:
+            self._a2a(self._rb, self._sb, self.out_splits, self.in_splits)
+        x.index_copy_(0, self.recv_all, self._rb)
+
+    exchange = forward
 
     def reverse_add(self, x):
         """owner entries of x += ghost copies held by the neighbours (ghost part is left untouched)"""
         if not self.peers:
             return
-        send = {}
-        for r, ix in self.recv_idx.items():
-            torch.index_select(x, 0, ix, out=self._rb[r])
-            send[r] = self._rb[r]
-        self._xfer(send, self._sb)
-        for r, ix in self.send_idx.items():
-            x.index_add_(0, ix, self._sb[r])
+        torch.index_select(x, 0, self.recv_all, out=self._rb)
+        if self.staged:
+            self._a2a(self._sb, self._rb, self.in_splits, self.out_splits, self._sh, self._rh)
+        else:
+            self._a2a(self._sb, self._rb, self.in_splits, self.out_splits)
+        x.index_add_(0, self.send_all, self._sb)
 
 
 class DistLevel:

@@ -267,81 +267,52 @@ def stacked_squares_local_mesh(N, size, rank, scale=1.0) -> LocalMesh:
 
 
 class HaloPlan:
-    """Send/receive DoF index lists per neighbouring rank (built once after the DoF layout is known)."""
+    """DoF-level halo of the solution-vector layout (built once after the DoF layout is known): ghost DoFs are the
+    4 unknowns of every ghost node, requested from the owner of the node's vertex by global vertex id and side."""
 
     def __init__(self, comm: Comm, lm: LocalMesh, node_i: np.ndarray, node_e: np.ndarray, device):
+        from .dist_amg import LevelHalo
         self.comm = comm
         self.device = device
-        self.peers = []
-        self.send_idx = {}
-        self.recv_idx = {}
-        if comm.size == 1:
-            return
-        nvo = lm.n_vertices_owned
-        ghosts = np.arange(nvo, lm.coords.shape[0])
-        requests = {}
-        for o in np.unique(lm.ghost_owner):
-            sel = ghosts[lm.ghost_owner == o]
-            has_i = node_i[sel] >= 0
-            has_e = node_e[sel] >= 0
-            requests[int(o)] = (lm.l2g[sel], has_i, has_e)
-            nodes = np.stack([node_i[sel], node_e[sel]], axis=1).ravel()
-            flags = np.stack([has_i, has_e], axis=1).ravel()
-            nodes = nodes[flags]
-            self.recv_idx[int(o)] = torch.as_tensor((4 * nodes[:, None] + np.arange(4)[None, :]).ravel(), dtype=torch.long, device=device)
-        gathered = comm.all_gather_object(requests)
-        owned_gid = lm.l2g[:nvo]
-        order = np.argsort(owned_gid, kind="stable")
-        sorted_gid = owned_gid[order]
-        for r, req in enumerate(gathered):
-            if r == comm.rank or comm.rank not in req:
-                continue
-            gids, has_i, has_e = req[comm.rank]
-            pos = np.searchsorted(sorted_gid, gids)
-            assert (pos < len(sorted_gid)).all() and (sorted_gid[pos] == gids).all(), "halo request for a vertex this rank does not own"
-            lv = order[pos]
-            nodes = np.stack([node_i[lv], node_e[lv]], axis=1).ravel()
-            flags = np.stack([has_i, has_e], axis=1).ravel()
-            nodes = nodes[flags]
-            assert (nodes >= 0).all(), "peer requests a node this rank does not have"
-            self.send_idx[r] = torch.as_tensor((4 * nodes[:, None] + np.arange(4)[None, :]).ravel(), dtype=torch.long, device=device)
-        self.peers = sorted(set(self.send_idx) | set(self.recv_idx))
-        self._sendbuf = {r: torch.empty(len(ix), dtype=torch.float64, device=device) for r, ix in self.send_idx.items()}
-        self._recvbuf = {r: torch.empty(len(ix), dtype=torch.float64, device=device) for r, ix in self.recv_idx.items()}
-        self.staged = comm.backend != "nccl" and torch.device(device).type == "cuda"
-        if self.staged:
-            self._sendhost = {r: torch.empty(len(ix), dtype=torch.float64).pin_memory() for r, ix in self.send_idx.items()}
-            self._recvhost = {r: torch.empty(len(ix), dtype=torch.float64).pin_memory() for r, ix in self.recv_idx.items()}
+        send_idx, recv_idx = {}, {}
+        if comm.size > 1:
+            nvo = lm.n_vertices_owned
+            ghosts = np.arange(nvo, lm.coords.shape[0])
+            requests = {}
+            for o in np.unique(lm.ghost_owner):
+                sel = ghosts[lm.ghost_owner == o]
+                has_i = node_i[sel] >= 0
+                has_e = node_e[sel] >= 0
+                requests[int(o)] = (lm.l2g[sel], has_i, has_e)
+                nodes = np.stack([node_i[sel], node_e[sel]], axis=1).ravel()
+                nodes = nodes[np.stack([has_i, has_e], axis=1).ravel()]
+                recv_idx[int(o)] = (4 * nodes[:, None] + np.arange(4)[None, :]).ravel()
+            gathered = comm.all_gather_object(requests)
+            owned_gid = lm.l2g[:nvo]
+            order = np.argsort(owned_gid, kind="stable")
+            sorted_gid = owned_gid[order]
+            for r, req in enumerate(gathered):
+                if r == comm.rank or comm.rank not in req:
+                    continue
+                gids, has_i, has_e = req[comm.rank]
+                pos = np.searchsorted(sorted_gid, gids)
+                assert (pos < len(sorted_gid)).all() and (sorted_gid[pos] == gids).all(), "halo request for a vertex this rank does not own"
+                lv = order[pos]
+                nodes = np.stack([node_i[lv], node_e[lv]], axis=1).ravel()
+                nodes = nodes[np.stack([has_i, has_e], axis=1).ravel()]
+                assert (nodes >= 0).all(), "peer requests a node this rank does not have"
+                send_idx[r] = (4 * nodes[:, None] + np.arange(4)[None, :]).ravel()
+        h = LevelHalo.__new__(LevelHalo)
+        h.comm, h.device = comm, device
+        h.n_own, h.n_loc = 0, 0
+        h._finish(send_idx, recv_idx)
+        self._h = h
+        self.peers = h.peers
+        self.send_idx, self.recv_idx = h.send_idx, h.recv_idx
 
     def exchange(self, x: torch.Tensor):
         """Fill the ghost entries of the local vector x (owned part first) from their owners."""
-        if not self.peers:
-            return
-        ops = []
-        for r in self.peers:
-            if r in self.send_idx:
-                torch.index_select(x, 0, self.send_idx[r], out=self._sendbuf[r])
-        if self.staged:
-            for r in self.send_idx:
-                self._sendhost[r].copy_(self._sendbuf[r])
-            torch.cuda.synchronize()
-            for r in self.peers:
-                if r in self.recv_idx:
-                    ops.append(dist.P2POp(dist.irecv, self._recvhost[r], r))
-                if r in self.send_idx:
-                    ops.append(dist.P2POp(dist.isend, self._sendhost[r], r))
-        else:
-            for r in self.peers:
-                if r in self.recv_idx:
-                    ops.append(dist.P2POp(dist.irecv, self._recvbuf[r], r))
-                if r in self.send_idx:
-                    ops.append(dist.P2POp(dist.isend, self._sendbuf[r], r))
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
-        for r in self.recv_idx:
-            if self.staged:
-                self._recvbuf[r].copy_(self._recvhost[r])
-            x.index_copy_(0, self.recv_idx[r], self._recvbuf[r])
+        self._h.forward(x)
 
 
 def all_reduce_sum_(t: torch.Tensor, comm: Comm):
