@@ -79,8 +79,8 @@ class LevelHalo:
             dist.all_to_all_single(out, inp, out_splits, in_splits)
 
     def forward(self, x):
-        """ghost entries of x <- owner values"""
-        if not self.peers:
+        """ghost entries of x <- owner values (collective: every rank calls it, also with nothing to exchange)"""
+        if self.comm.size <= 1:
             return
         torch.index_select(x, 0, self.send_all, out=self._sb)
         if self.staged:
@@ -92,8 +92,8 @@ class LevelHalo:
     exchange = forward
 
     def reverse_add(self, x):
-        """owner entries of x += ghost copies held by the neighbours (ghost part is left untouched)"""
-        if not self.peers:
+        """owner entries of x += ghost copies held by the neighbours (ghost part is left untouched); collective"""
+        if self.comm.size <= 1:
             return
         torch.index_select(x, 0, self.recv_all, out=self._rb)
         if self.staged:

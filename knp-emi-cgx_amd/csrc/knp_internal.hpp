@@ -113,10 +113,9 @@ struct knp_ctx {
     int32_t *d_gptr = nullptr, *d_gcol = nullptr, *d_grow = nullptr, *d_gq_i = nullptr, *d_gq_e = nullptr,
             *d_gdiag = nullptr;
     int32_t *d_gcptr = nullptr, *d_gc_facet = nullptr, *d_gc_lab = nullptr;
-    // CSR of A and P
+    // CSR of A; P pair-major (p_vals[4*pair + field])
     int32_t *d_rowptr = nullptr, *d_colind = nullptr;
     double* d_vals = nullptr;
-    int32_t *d_p_rowptr = nullptr, *d_p_colind = nullptr;
     double* d_p_vals = nullptr;
     bool have_A = false, have_P = false, have_cc = false;
     // work arrays

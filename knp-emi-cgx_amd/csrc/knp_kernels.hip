@@ -1397,7 +1397,7 @@ int knp_destroy(knp_ctx* ctx) {
     dev_free(ctx->d_gptr); dev_free(ctx->d_gcol); dev_free(ctx->d_grow); dev_free(ctx->d_gq_i); dev_free(ctx->d_gq_e);
     dev_free(ctx->d_gdiag); dev_free(ctx->d_gcptr); dev_free(ctx->d_gc_facet); dev_free(ctx->d_gc_lab);
     dev_free(ctx->d_rowptr); dev_free(ctx->d_colind); dev_free(ctx->d_vals);
-    dev_free(ctx->d_p_rowptr); dev_free(ctx->d_p_colind); dev_free(ctx->d_p_vals);
+    dev_free(ctx->d_p_vals);
     dev_free(ctx->d_cbar); dev_free(ctx->d_fmat); dev_free(ctx->d_fvec);
     dev_free(ctx->d_partial); dev_free(ctx->d_red); dev_free(ctx->d_y); dev_free(ctx->d_vbj);
     if (ctx->h_red) (void)hipHostFree(ctx->h_red);
@@ -1937,7 +1937,6 @@ int knp_amg_set_level(knp_ctx* ctx, int32_t hier, int32_t level, int32_t n_rows,
     HIPCHK(hipMalloc((void**)&L.x, (size_t)n_loc * sizeof(double)));
     HIPCHK(hipMalloc((void**)&L.b, (size_t)n_loc * sizeof(double)));
     HIPCHK(hipMemset(L.b, 0, (size_t)n_loc * sizeof(double)));
-    HIPCHK(hipMemset(L.r, 0, 0));
     HIPCHK(hipMalloc((void**)&L.r, (size_t)n_loc * sizeof(double)));
     HIPCHK(hipMalloc((void**)&L.d, (size_t)n_loc * sizeof(double)));
     HIPCHK(hipMalloc((void**)&L.r2, (size_t)n_loc * sizeof(double)));

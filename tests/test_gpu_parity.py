@@ -234,3 +234,68 @@ def test_cube_run_matches_oracle():
     assert abs(ni - oi) <= 1e-6 * oi
     gam = (o.lay.node_i >= 0) & (o.lay.node_e >= 0)
     assert np.allclose(s.problem.phi_m_prev.numpy()[gam], o.phi_m[gam], rtol=1e-6)
+
+
+def test_abi_argument_validation():
+    """Error convention of the C ABI: negative return code + message, never a crash (include/knpemi_hip.h)."""
+    import ctypes as C
+    from cgx_hip import _lib
+    p, be, o = _setup(8, "square", perturb=False)
+    lib = be.lib
+    # bad parameters
+    z = (C.c_double * 3)(1, 1, 0)
+    d = (C.c_double * 3)(1, 1, 1)
+    assert lib.knp_set_params(be.ctx, 1e-5, 1.0, 1.0, 1.0, 3, z, d, d) == -1          # zero valence
+    assert b"valence" in lib.knp_last_error(be.ctx)
+    assert lib.knp_set_params(be.ctx, -1.0, 1.0, 1.0, 1.0, 3, d, d, d) == -1
+    assert lib.knp_set_params(be.ctx, 1e-5, 1.0, 1.0, 1.0, 2, d, d, d) == -1          # n_ions != 3
+    be.set_params()                                                                    # restore
+    # invalid bytecode: register out of range, unknown constant
+    bad = (C.c_int32 * 4)(6, 99, 0, 0)
+    assert lib.knp_set_program(be.ctx, 0, 1, bad, 0, None) == -1
+    bad = (C.c_int32 * 4)(0, 0, 5, 0)
+    assert lib.knp_set_program(be.ctx, 0, 1, bad, 1, (C.c_double * 1)(1.0)) == -1
+    be.upload_programs()
+    # solve before assembly -> state error, not a crash
+    p2, be2, _ = _setup(8, "square", perturb=False)
+    its, rn, reason = C.c_int32(), C.c_double(), C.c_int32()
+    rc = lib.knp_gmres_solve(be2.ctx, be2.b.data_ptr(), be2.x.data_ptr(), 1e-9, 1e-50, 10, 30, C.byref(its), C.byref(rn), C.byref(reason))
+    assert rc == -3 and b"not assembled" in lib.knp_last_error(be2.ctx)
+    # restart out of range
+    be.assemble_matrix()
+    rc = lib.knp_gmres_solve(be.ctx, be.b.data_ptr(), be.x.data_ptr(), 1e-9, 1e-50, 10, 500, C.byref(its), C.byref(rn), C.byref(reason))
+    assert rc == -1
+    # Dirichlet dof out of range
+    bad = (C.c_int32 * 1)(10 ** 8)
+    assert lib.knp_set_dirichlet(be.ctx, 1, bad) == -1
+    # AMG selected without a hierarchy
+    assert lib.knp_pc_setup(be2.ctx, 2) == -3
+    # non-convergence is a reason code, not an error
+    be.assemble_rhs()
+    rc = lib.knp_gmres_solve(be.ctx, be.b.data_ptr(), be.x.data_ptr(), 1e-30, 1e-300, 2, 30, C.byref(its), C.byref(rn), C.byref(reason))
+    assert rc == 0 and reason.value == -3 and its.value == 2
+
+
+def test_mesh_validation_in_knp_create():
+    import ctypes as C
+    from cgx_hip import _lib
+    from cgx_hip._lib import MeshDesc
+    lib = _lib.load()
+    coords = np.array([[0, 0], [1, 0], [0, 1]], dtype=np.float64)
+    cells = np.array([[0, 1, 5]], dtype=np.int32)                       # vertex index out of range
+    side = np.zeros(1, dtype=np.uint8)
+    q = np.array([[0.5, 0.5]]); w = np.array([1.0])
+    d = MeshDesc(dim=2, n_vertices=3, n_vertices_owned=3, n_cells=1, n_cells_owned=1,
+                 cells=cells.ctypes.data_as(_lib.i32p), coords=coords.ctypes.data_as(_lib.f64p),
+                 cell_side=side.ctypes.data_as(_lib.u8p), n_gamma=0, gamma=None, gamma_prog=None,
+                 n_q=1, q_pts=q.ctypes.data_as(_lib.f64p), q_w=w.ctypes.data_as(_lib.f64p))
+    ctx = C.c_void_p()
+    rc = lib.knp_create(C.byref(ctx), C.byref(d))
+    assert rc == -5 and b"out of range" in lib.knp_last_error(ctx)
+    lib.knp_destroy(ctx)
+    cells[0, 2] = 2
+    coords[2] = [2, 0]                                                  # degenerate (collinear) cell
+    ctx = C.c_void_p()
+    rc = lib.knp_create(C.byref(ctx), C.byref(d))
+    assert rc == -5 and b"degenerate" in lib.knp_last_error(ctx)
+    lib.knp_destroy(ctx)
