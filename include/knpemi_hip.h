@@ -208,6 +208,10 @@ int knp_amg_set_coarse(knp_ctx* ctx, int32_t hier, int32_t n, const double* dens
 /* level 0 == the library's own P (owned block): use its pair-major storage and node kernels instead of the uploaded
  * CSR. mode: 0 off, 1 all four fields, 2 ion fields only, 3 potential only */
 int knp_amg_use_native_level0(knp_ctx* ctx, int32_t hier, int32_t mode);
+/* mixed-precision preconditioner: level operators, transfer operators and P on level 0 are STORED in fp32
+ * (converted on load); every vector, the dense coarse inverse, the system matrix and the Krylov process stay fp64.
+ * Call before uploading a hierarchy. */
+int knp_amg_set_precision(knp_ctx* ctx, int32_t fp32_storage);
 int knp_gmres_solve(knp_ctx* ctx, const double* b, double* x, double rtol, double atol, int32_t max_it,
                     int32_t restart, int32_t* its, double* rnorm, int32_t* reason);
 

@@ -88,6 +88,7 @@ SIGNATURES = {
     "knp_amg_set_level_mode": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "knp_amg_set_coarse": (C.c_int, [vp, C.c_int32, C.c_int32, f64p]),
     "knp_amg_use_native_level0": (C.c_int, [vp, C.c_int32, C.c_int32]),
+    "knp_amg_set_precision": (C.c_int, [vp, C.c_int32]),
     "knp_gmres_solve": (C.c_int, [vp, vp, vp, C.c_double, C.c_double, C.c_int32, C.c_int32, i32p, f64p, i32p]),
     "knp_pack": (C.c_int, [vp, C.POINTER(FieldsOut), vp]),
     "knp_unpack": (C.c_int, [vp, vp, C.POINTER(FieldsOut)]),

@@ -81,6 +81,7 @@ class SolverKNPEMI:
     amg_post = 1
     amg_coarse_size = 2500
     amg_replicate_below = 300000
+    amg_fp32 = True        # mixed-precision preconditioner storage (operators fp32, vectors/Krylov fp64)
 
     def __init__(self, problem: ProblemKNPEMI, solver_config: dict):
         self.problem = problem
@@ -112,7 +113,7 @@ class SolverKNPEMI:
             if "ksp_max_it" in ks: self.ksp_max_it = int(ks["ksp_max_it"])
             if "gmres_restart" in ks: self.gmres_restart = int(ks["gmres_restart"])
             if "strict" in ks: self.strict = bool(ks["strict"])
-            for k in ("amg_theta", "amg_cheby_degree", "amg_pre", "amg_post", "amg_coarse_size", "amg_replicate_below"):
+            for k in ("amg_theta", "amg_cheby_degree", "amg_pre", "amg_post", "amg_coarse_size", "amg_replicate_below", "amg_fp32"):
                 if k in ks: setattr(self, k, type(getattr(self, k))(ks[k]))
         if self.ksp_type != "gmres":
             raise NotImplementedError(f"ksp_type '{self.ksp_type}': only 'gmres' is implemented natively.")
@@ -154,6 +155,7 @@ class SolverKNPEMI:
         be.assemble_precond()
         if self._pc_kind in (_lib.PC_AMG, _lib.PC_AMG_BT):
             tic = time.perf_counter()
+            be.check(be.lib.knp_amg_set_precision(be.ctx, 1 if self.amg_fp32 else 0))
             P = be.precond_csr()
             if self.comm.size > 1 and os.environ.get("KNP_DIST_PC", "global") != "bj":
                 self._assemble_distributed_amg(P)

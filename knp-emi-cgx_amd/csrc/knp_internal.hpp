@@ -63,6 +63,7 @@ struct KnpAmgLevel {
     int repl_n = 0;  // > 0: the next level is replicated on all ranks with this many unknowns (all-reduce after restriction)
     int32_t *A_rp = nullptr, *A_ci = nullptr;
     double* A_v = nullptr;
+    float *A_vf = nullptr, *P_vf = nullptr, *R_vf = nullptr;   // fp32 copies (mixed-precision preconditioner storage)
     double* inv_diag = nullptr;
     double lambda_max = 1.0;
     int32_t *P_rp = nullptr, *P_ci = nullptr;
@@ -80,6 +81,7 @@ struct KnpAmgHier {
     KnpAmgLevel lv[KNP_MAX_AMG_LEVELS];
     int nc = 0;
     double* cinv = nullptr;
+    float* cinv_f = nullptr;
 };
 
 struct knp_ctx {
@@ -137,6 +139,8 @@ struct knp_ctx {
     int pc_kind = KNP_PC_NONE;
     double* d_vbj = nullptr;  // [n_nodes_owned*16] compact vertex blocks
     KnpAmgHier hier[KNP_MAX_HIER];   // 0: all fields (block-Jacobi form) or ion fields; 1: potential
+    int amg_fp32 = 0;                // store the preconditioner's operators in fp32 (vectors and A stay fp64)
+    float* d_p_vals_f = nullptr;     // fp32 shadow of the pair-major P
     double* d_ML = nullptr;          // [n_nodes_owned] lumped mass of each node
     double* d_cc = nullptr;          // [n_nodes_owned] diagonal Schur term psi / (sum_j z_j^2 k_j) / ML
     double *d_t2 = nullptr, *d_w2 = nullptr;  // work vectors of the block-triangular preconditioner

@@ -478,9 +478,9 @@ k_rhs(int n_nodes_owned, int n_g, int dim, double dt, const int32_t* __restrict_
 // ------------------------------------------------------------------------------------------
 // K4: CSR SpMV, L lanes per row.  mode 0: y = A x ; mode 1: y = b - A x ; mode 2: y += A x
 // ------------------------------------------------------------------------------------------
-template <int L, int MODE, int TAG>   // TAG 1 = the system matrix A (own symbol for profilers), 0 = AMG level operators
+template <int L, int MODE, int TAG, typename VT = double>   // TAG 1 = the system matrix A, 0 = AMG level operators (VT float: fp32-stored)
 __global__ void __launch_bounds__(NT)
-k_spmv(int n_rows, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci, const double* __restrict__ v,
+k_spmv(int n_rows, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci, const VT* __restrict__ v,
        const double* __restrict__ x, const double* __restrict__ b, double* __restrict__ y) {
     const int gid = blockIdx.x * NT + threadIdx.x;
     const int row = gid / L;
@@ -488,7 +488,7 @@ k_spmv(int n_rows, const int32_t* __restrict__ rp, const int32_t* __restrict__ c
     double s = 0.0;
     if (row < n_rows) {
         const int e = rp[row + 1];
-        for (int k = rp[row] + lane; k < e; k += L) s += v[k] * x[ci[k]];
+        for (int k = rp[row] + lane; k < e; k += L) s += (double)v[k] * x[ci[k]];
     }
 #pragma unroll
     for (int o = L >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, L);
@@ -583,10 +583,10 @@ static void launch_spmv_node(hipStream_t st, int G, int n_nodes, const int32_t* 
 //   MODE 0: Chebyshev step  d = c1*d + c2*Dinv*(b - P xin), xout = xin + d
 //   MODE 1: residual        xout = b - P xin
 // ------------------------------------------------------------------------------------------
-template <int G, int MODE, int FM>   // FM field mask: 0 all four fields, 1 ion fields only, 2 potential only
+template <int G, int MODE, int FM, typename VT>   // FM field mask: 0 all four fields, 1 ion fields only, 2 potential only
 __global__ void __launch_bounds__(NT)
 k_pnode(int n_nodes, int n_col_nodes, const int32_t* __restrict__ pair_ptr, const int32_t* __restrict__ pair_col,
-        const double* __restrict__ pv, const double* __restrict__ dinv, const double* __restrict__ b,
+        const VT* __restrict__ pv, const double* __restrict__ dinv, const double* __restrict__ b,
         const double* __restrict__ xin, double c1, double c2, double* __restrict__ d, double* __restrict__ xout) {
     const int node = (blockIdx.x * NT + threadIdx.x) / G;
     const int lane = threadIdx.x & (G - 1);
@@ -598,15 +598,22 @@ k_pnode(int n_nodes, int n_col_nodes, const int32_t* __restrict__ pair_ptr, cons
             const int nb = pair_col[p0 + q];
             if (nb < n_col_nodes) {
                 const double2 xb = *reinterpret_cast<const double2*>(xin + 4 * (size_t)nb + 2);
-                const double2 c = *reinterpret_cast<const double2*>(pv + 4 * (size_t)(p0 + q) + 2);
+                double a0, a1, c0, c1v;
+                if (sizeof(VT) == 4) {
+                    const float4 pq = *reinterpret_cast<const float4*>(pv + 4 * (size_t)(p0 + q));
+                    a0 = pq.x; a1 = pq.y; c0 = pq.z; c1v = pq.w;
+                } else {
+                    const double2 a = *reinterpret_cast<const double2*>(pv + 4 * (size_t)(p0 + q));
+                    const double2 c = *reinterpret_cast<const double2*>(pv + 4 * (size_t)(p0 + q) + 2);
+                    a0 = a.x; a1 = a.y; c0 = c.x; c1v = c.y;
+                }
                 if (FM != 2) {
                     const double2 xa = *reinterpret_cast<const double2*>(xin + 4 * (size_t)nb);
-                    const double2 a = *reinterpret_cast<const double2*>(pv + 4 * (size_t)(p0 + q));
-                    s0 += a.x * xa.x;
-                    s1 += a.y * xa.y;
-                    s2 += c.x * xb.x;
+                    s0 += a0 * xa.x;
+                    s1 += a1 * xa.y;
+                    s2 += c0 * xb.x;
                 }
-                if (FM != 1) s3 += c.y * xb.y;
+                if (FM != 1) s3 += c1v * xb.y;
             }
         }
     }
@@ -646,23 +653,33 @@ k_pnode(int n_nodes, int n_col_nodes, const int32_t* __restrict__ pair_ptr, cons
         }
     }
 }
-template <int MODE, int FM>
-static void launch_pnode_fm(hipStream_t st, int G, int n_nodes, int ncn, const int32_t* pp, const int32_t* pc, const double* pv,
+template <int MODE, int FM, typename VT>
+static void launch_pnode_fm(hipStream_t st, int G, int n_nodes, int ncn, const int32_t* pp, const int32_t* pc, const VT* pv,
                             const double* dinv, const double* b, const double* xin, double c1, double c2, double* d, double* xout) {
     switch (G) {
-        case 4: hipLaunchKernelGGL((k_pnode<4, MODE, FM>), dim3(nblocks((int64_t)n_nodes * 4)), dim3(NT), 0, st, n_nodes, ncn, pp, pc, pv, dinv, b, xin, c1, c2, d, xout); break;
-        case 8: hipLaunchKernelGGL((k_pnode<8, MODE, FM>), dim3(nblocks((int64_t)n_nodes * 8)), dim3(NT), 0, st, n_nodes, ncn, pp, pc, pv, dinv, b, xin, c1, c2, d, xout); break;
-        case 16: hipLaunchKernelGGL((k_pnode<16, MODE, FM>), dim3(nblocks((int64_t)n_nodes * 16)), dim3(NT), 0, st, n_nodes, ncn, pp, pc, pv, dinv, b, xin, c1, c2, d, xout); break;
-        default: hipLaunchKernelGGL((k_pnode<32, MODE, FM>), dim3(nblocks((int64_t)n_nodes * 32)), dim3(NT), 0, st, n_nodes, ncn, pp, pc, pv, dinv, b, xin, c1, c2, d, xout); break;
+        case 4: hipLaunchKernelGGL((k_pnode<4, MODE, FM, VT>), dim3(nblocks((int64_t)n_nodes * 4)), dim3(NT), 0, st, n_nodes, ncn, pp, pc, pv, dinv, b, xin, c1, c2, d, xout); break;
+        case 8: hipLaunchKernelGGL((k_pnode<8, MODE, FM, VT>), dim3(nblocks((int64_t)n_nodes * 8)), dim3(NT), 0, st, n_nodes, ncn, pp, pc, pv, dinv, b, xin, c1, c2, d, xout); break;
+        case 16: hipLaunchKernelGGL((k_pnode<16, MODE, FM, VT>), dim3(nblocks((int64_t)n_nodes * 16)), dim3(NT), 0, st, n_nodes, ncn, pp, pc, pv, dinv, b, xin, c1, c2, d, xout); break;
+        default: hipLaunchKernelGGL((k_pnode<32, MODE, FM, VT>), dim3(nblocks((int64_t)n_nodes * 32)), dim3(NT), 0, st, n_nodes, ncn, pp, pc, pv, dinv, b, xin, c1, c2, d, xout); break;
     }
+}
+template <int MODE, typename VT>
+static void launch_pnode_t(hipStream_t st, int fm, int G, int n_nodes, int ncn, const int32_t* pp, const int32_t* pc, const VT* pv,
+                           const double* dinv, const double* b, const double* xin, double c1, double c2, double* d, double* xout) {
+    if (n_nodes <= 0) return;
+    if (fm == 1) launch_pnode_fm<MODE, 1, VT>(st, G, n_nodes, ncn, pp, pc, pv, dinv, b, xin, c1, c2, d, xout);
+    else if (fm == 2) launch_pnode_fm<MODE, 2, VT>(st, G, n_nodes, ncn, pp, pc, pv, dinv, b, xin, c1, c2, d, xout);
+    else launch_pnode_fm<MODE, 0, VT>(st, G, n_nodes, ncn, pp, pc, pv, dinv, b, xin, c1, c2, d, xout);
 }
 template <int MODE>
 static void launch_pnode(hipStream_t st, int fm, int G, int n_nodes, int ncn, const int32_t* pp, const int32_t* pc, const double* pv,
-                         const double* dinv, const double* b, const double* xin, double c1, double c2, double* d, double* xout) {
-    if (n_nodes <= 0) return;
-    if (fm == 1) launch_pnode_fm<MODE, 1>(st, G, n_nodes, ncn, pp, pc, pv, dinv, b, xin, c1, c2, d, xout);
-    else if (fm == 2) launch_pnode_fm<MODE, 2>(st, G, n_nodes, ncn, pp, pc, pv, dinv, b, xin, c1, c2, d, xout);
-    else launch_pnode_fm<MODE, 0>(st, G, n_nodes, ncn, pp, pc, pv, dinv, b, xin, c1, c2, d, xout);
+                         const float* pvf, const double* dinv, const double* b, const double* xin, double c1, double c2, double* d, double* xout) {
+    if (pvf) launch_pnode_t<MODE, float>(st, fm, G, n_nodes, ncn, pp, pc, pvf, dinv, b, xin, c1, c2, d, xout);
+    else launch_pnode_t<MODE, double>(st, fm, G, n_nodes, ncn, pp, pc, pv, dinv, b, xin, c1, c2, d, xout);
+}
+
+__global__ void __launch_bounds__(NT) k_to_float(int64_t n, const double* __restrict__ in, float* __restrict__ out) {
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < n; e += (int64_t)gridDim.x * NT) out[e] = (float)in[e];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -721,18 +738,30 @@ k_schur_diag(int n_nodes, double psi, double z0, double z1, double z2, const int
     cc[n] = psi / (s * ML[n]);
 }
 
+template <int MODE, int TAG, typename VT>
+static void launch_spmv_t(hipStream_t st, int lanes, int n_rows, const int32_t* rp, const int32_t* ci,
+                          const VT* v, const double* x, const double* b, double* y) {
+    if (n_rows <= 0) return;
+    switch (lanes) {
+        case 2: hipLaunchKernelGGL((k_spmv<2, MODE, TAG, VT>), dim3(nblocks((int64_t)n_rows * 2)), dim3(NT), 0, st, n_rows, rp, ci, v, x, b, y); break;
+        case 4: hipLaunchKernelGGL((k_spmv<4, MODE, TAG, VT>), dim3(nblocks((int64_t)n_rows * 4)), dim3(NT), 0, st, n_rows, rp, ci, v, x, b, y); break;
+        case 8: hipLaunchKernelGGL((k_spmv<8, MODE, TAG, VT>), dim3(nblocks((int64_t)n_rows * 8)), dim3(NT), 0, st, n_rows, rp, ci, v, x, b, y); break;
+        case 16: hipLaunchKernelGGL((k_spmv<16, MODE, TAG, VT>), dim3(nblocks((int64_t)n_rows * 16)), dim3(NT), 0, st, n_rows, rp, ci, v, x, b, y); break;
+        case 32: hipLaunchKernelGGL((k_spmv<32, MODE, TAG, VT>), dim3(nblocks((int64_t)n_rows * 32)), dim3(NT), 0, st, n_rows, rp, ci, v, x, b, y); break;
+        default: hipLaunchKernelGGL((k_spmv<64, MODE, TAG, VT>), dim3(nblocks((int64_t)n_rows * 64)), dim3(NT), 0, st, n_rows, rp, ci, v, x, b, y); break;
+    }
+}
 template <int MODE, int TAG = 0>
 static void launch_spmv(hipStream_t st, int lanes, int n_rows, const int32_t* rp, const int32_t* ci,
                         const double* v, const double* x, const double* b, double* y) {
-    if (n_rows <= 0) return;
-    switch (lanes) {
-        case 2: hipLaunchKernelGGL((k_spmv<2, MODE, TAG>), dim3(nblocks((int64_t)n_rows * 2)), dim3(NT), 0, st, n_rows, rp, ci, v, x, b, y); break;
-        case 4: hipLaunchKernelGGL((k_spmv<4, MODE, TAG>), dim3(nblocks((int64_t)n_rows * 4)), dim3(NT), 0, st, n_rows, rp, ci, v, x, b, y); break;
-        case 8: hipLaunchKernelGGL((k_spmv<8, MODE, TAG>), dim3(nblocks((int64_t)n_rows * 8)), dim3(NT), 0, st, n_rows, rp, ci, v, x, b, y); break;
-        case 16: hipLaunchKernelGGL((k_spmv<16, MODE, TAG>), dim3(nblocks((int64_t)n_rows * 16)), dim3(NT), 0, st, n_rows, rp, ci, v, x, b, y); break;
-        case 32: hipLaunchKernelGGL((k_spmv<32, MODE, TAG>), dim3(nblocks((int64_t)n_rows * 32)), dim3(NT), 0, st, n_rows, rp, ci, v, x, b, y); break;
-        default: hipLaunchKernelGGL((k_spmv<64, MODE, TAG>), dim3(nblocks((int64_t)n_rows * 64)), dim3(NT), 0, st, n_rows, rp, ci, v, x, b, y); break;
-    }
+    launch_spmv_t<MODE, TAG, double>(st, lanes, n_rows, rp, ci, v, x, b, y);
+}
+// AMG level operator stored in fp64 (v) or fp32 (vf != nullptr)
+template <int MODE>
+static void launch_spmv_mp(hipStream_t st, int lanes, int n_rows, const int32_t* rp, const int32_t* ci,
+                           const double* v, const float* vf, const double* x, const double* b, double* y) {
+    if (vf) launch_spmv_t<MODE, 0, float>(st, lanes, n_rows, rp, ci, vf, x, b, y);
+    else launch_spmv_t<MODE, 0, double>(st, lanes, n_rows, rp, ci, v, x, b, y);
 }
 
 static int pick_lanes(double avg_nnz_per_row) {
@@ -1031,9 +1060,9 @@ k_vbj_apply(int n_nodes_owned, const uint8_t* __restrict__ node_side, const int3
 // ------------------------------------------------------------------------------------------
 // One Chebyshev step with the solution update fused (ping-pong buffers xin -> xout):
 //   d = c1*d + c2 * Dinv*(b - A xin) ;  xout = xin + d          (L lanes per row)
-template <int L>
+template <int L, typename VT>
 __global__ void __launch_bounds__(NT)
-k_cheby_step(int n_rows, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci, const double* __restrict__ v,
+k_cheby_step(int n_rows, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci, const VT* __restrict__ v,
              const double* __restrict__ dinv, const double* __restrict__ b, const double* __restrict__ xin,
              double c1, double c2, double* __restrict__ d, double* __restrict__ xout) {
     const int gid = blockIdx.x * NT + threadIdx.x;
@@ -1042,7 +1071,7 @@ k_cheby_step(int n_rows, const int32_t* __restrict__ rp, const int32_t* __restri
     double s = 0.0;
     if (row < n_rows) {
         const int e = rp[row + 1];
-        for (int k = rp[row] + lane; k < e; k += L) s += v[k] * xin[ci[k]];
+        for (int k = rp[row] + lane; k < e; k += L) s += (double)v[k] * xin[ci[k]];
     }
 #pragma unroll
     for (int o = L >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, L);
@@ -1052,17 +1081,23 @@ k_cheby_step(int n_rows, const int32_t* __restrict__ rp, const int32_t* __restri
         xout[row] = xin[row] + dn;
     }
 }
-static void launch_cheby(hipStream_t st, int lanes, int n_rows, const int32_t* rp, const int32_t* ci, const double* v,
-                         const double* dinv, const double* b, const double* xin, double c1, double c2, double* d, double* xout) {
+template <typename VT>
+static void launch_cheby_t(hipStream_t st, int lanes, int n_rows, const int32_t* rp, const int32_t* ci, const VT* v,
+                           const double* dinv, const double* b, const double* xin, double c1, double c2, double* d, double* xout) {
     if (n_rows <= 0) return;
     switch (lanes) {
-        case 2: hipLaunchKernelGGL((k_cheby_step<2>), dim3(nblocks((int64_t)n_rows * 2)), dim3(NT), 0, st, n_rows, rp, ci, v, dinv, b, xin, c1, c2, d, xout); break;
-        case 4: hipLaunchKernelGGL((k_cheby_step<4>), dim3(nblocks((int64_t)n_rows * 4)), dim3(NT), 0, st, n_rows, rp, ci, v, dinv, b, xin, c1, c2, d, xout); break;
-        case 8: hipLaunchKernelGGL((k_cheby_step<8>), dim3(nblocks((int64_t)n_rows * 8)), dim3(NT), 0, st, n_rows, rp, ci, v, dinv, b, xin, c1, c2, d, xout); break;
-        case 16: hipLaunchKernelGGL((k_cheby_step<16>), dim3(nblocks((int64_t)n_rows * 16)), dim3(NT), 0, st, n_rows, rp, ci, v, dinv, b, xin, c1, c2, d, xout); break;
-        case 32: hipLaunchKernelGGL((k_cheby_step<32>), dim3(nblocks((int64_t)n_rows * 32)), dim3(NT), 0, st, n_rows, rp, ci, v, dinv, b, xin, c1, c2, d, xout); break;
-        default: hipLaunchKernelGGL((k_cheby_step<64>), dim3(nblocks((int64_t)n_rows * 64)), dim3(NT), 0, st, n_rows, rp, ci, v, dinv, b, xin, c1, c2, d, xout); break;
+        case 2: hipLaunchKernelGGL((k_cheby_step<2, VT>), dim3(nblocks((int64_t)n_rows * 2)), dim3(NT), 0, st, n_rows, rp, ci, v, dinv, b, xin, c1, c2, d, xout); break;
+        case 4: hipLaunchKernelGGL((k_cheby_step<4, VT>), dim3(nblocks((int64_t)n_rows * 4)), dim3(NT), 0, st, n_rows, rp, ci, v, dinv, b, xin, c1, c2, d, xout); break;
+        case 8: hipLaunchKernelGGL((k_cheby_step<8, VT>), dim3(nblocks((int64_t)n_rows * 8)), dim3(NT), 0, st, n_rows, rp, ci, v, dinv, b, xin, c1, c2, d, xout); break;
+        case 16: hipLaunchKernelGGL((k_cheby_step<16, VT>), dim3(nblocks((int64_t)n_rows * 16)), dim3(NT), 0, st, n_rows, rp, ci, v, dinv, b, xin, c1, c2, d, xout); break;
+        case 32: hipLaunchKernelGGL((k_cheby_step<32, VT>), dim3(nblocks((int64_t)n_rows * 32)), dim3(NT), 0, st, n_rows, rp, ci, v, dinv, b, xin, c1, c2, d, xout); break;
+        default: hipLaunchKernelGGL((k_cheby_step<64, VT>), dim3(nblocks((int64_t)n_rows * 64)), dim3(NT), 0, st, n_rows, rp, ci, v, dinv, b, xin, c1, c2, d, xout); break;
     }
+}
+static void launch_cheby(hipStream_t st, int lanes, int n_rows, const int32_t* rp, const int32_t* ci, const double* v, const float* vf,
+                         const double* dinv, const double* b, const double* xin, double c1, double c2, double* d, double* xout) {
+    if (vf) launch_cheby_t<float>(st, lanes, n_rows, rp, ci, vf, dinv, b, xin, c1, c2, d, xout);
+    else launch_cheby_t<double>(st, lanes, n_rows, rp, ci, v, dinv, b, xin, c1, c2, d, xout);
 }
 // first Chebyshev step from a zero guess: d = x = c * Dinv * b
 __global__ void __launch_bounds__(NT) k_cheby_first(int n, double c, const double* __restrict__ dinv,
@@ -1075,13 +1110,14 @@ __global__ void __launch_bounds__(NT) k_cheby_first(int n, double c, const doubl
     }
 }
 // y = M x, dense row-major n x n, one wave per row
-__global__ void __launch_bounds__(NT) k_dense_matvec(int n, const double* __restrict__ M, const double* __restrict__ x,
+template <typename VT>
+__global__ void __launch_bounds__(NT) k_dense_matvec(int n, const VT* __restrict__ M, const double* __restrict__ x,
                                                      double* __restrict__ y) {
     const int row = (blockIdx.x * NT + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     double s = 0.0;
     if (row < n)
-        for (int k = lane; k < n; k += 64) s += M[(size_t)row * n + k] * x[k];
+        for (int k = lane; k < n; k += 64) s += (double)M[(size_t)row * n + k] * x[k];
     s = wave_sum(s);
     if (lane == 0 && row < n) y[row] = s;
 }
@@ -1411,10 +1447,12 @@ int knp_destroy(knp_ctx* ctx) {
             KnpAmgLevel& L = H.lv[l];
             dev_free(L.A_rp); dev_free(L.A_ci); dev_free(L.A_v); dev_free(L.inv_diag);
             dev_free(L.P_rp); dev_free(L.P_ci); dev_free(L.P_v); dev_free(L.R_rp); dev_free(L.R_ci); dev_free(L.R_v);
+            dev_free(L.A_vf); dev_free(L.P_vf); dev_free(L.R_vf);
             dev_free(L.x); dev_free(L.b); dev_free(L.r); dev_free(L.d); dev_free(L.r2);
         }
-        dev_free(H.cinv);
+        dev_free(H.cinv); dev_free(H.cinv_f);
     }
+    dev_free(ctx->d_p_vals_f);
     dev_free(ctx->d_ML); dev_free(ctx->d_cc); dev_free(ctx->d_t2); dev_free(ctx->d_w2);
     dev_free(ctx->d_defl_mode); dev_free(ctx->d_defl_einv); dev_free(ctx->d_bc_dofs);
     delete ctx;
@@ -1883,10 +1921,11 @@ static void free_hier(KnpAmgHier& H) {
         KnpAmgLevel& L = H.lv[l];
         dev_free(L.A_rp); dev_free(L.A_ci); dev_free(L.A_v); dev_free(L.inv_diag);
         dev_free(L.P_rp); dev_free(L.P_ci); dev_free(L.P_v); dev_free(L.R_rp); dev_free(L.R_ci); dev_free(L.R_v);
+        dev_free(L.A_vf); dev_free(L.P_vf); dev_free(L.R_vf);
         dev_free(L.x); dev_free(L.b); dev_free(L.r); dev_free(L.d); dev_free(L.r2);
         L.n = L.n_coarse = 0;
     }
-    dev_free(H.cinv);
+    dev_free(H.cinv); dev_free(H.cinv_f);
     H.nc = 0; H.levels = 0; H.native0 = 0;
 }
 int knp_amg_reset(knp_ctx* ctx, int32_t hier, int32_t n_levels, int32_t pre, int32_t post, int32_t cheby) {
@@ -1915,7 +1954,12 @@ int knp_amg_set_level(knp_ctx* ctx, int32_t hier, int32_t level, int32_t n_rows,
     L.n = n_rows; L.n_loc = n_loc; L.n_coarse = n_coarse; L.lambda_max = lambda_max;
     KCHK(dev_upload_raw(ctx, &L.A_rp, A_rp, (size_t)n_rows + 1));
     KCHK(dev_upload_raw(ctx, &L.A_ci, A_ci, (size_t)nnzA));
-    KCHK(dev_upload_raw(ctx, &L.A_v, A_v, (size_t)nnzA));
+    if (ctx->amg_fp32) {   // one copy only: fp32 when the preconditioner is stored in mixed precision
+        std::vector<float> tmp(A_v, A_v + nnzA);
+        KCHK(dev_upload(ctx, &L.A_vf, tmp));
+    } else {
+        KCHK(dev_upload_raw(ctx, &L.A_v, A_v, (size_t)nnzA));
+    }
     KCHK(dev_upload_raw(ctx, &L.inv_diag, inv_diag, (size_t)n_rows));
     L.A_lanes = pick_lanes((double)nnzA / n_rows);
     if (n_coarse > 0) {
@@ -1927,10 +1971,16 @@ int knp_amg_set_level(knp_ctx* ctx, int32_t hier, int32_t level, int32_t n_rows,
             if (R_ci[k] < 0 || R_ci[k] >= n_rows) { ctx->err = "AMG restrictor column out of range"; return KNP_E_ARG; }
         KCHK(dev_upload_raw(ctx, &L.P_rp, P_rp, (size_t)n_rows + 1));
         KCHK(dev_upload_raw(ctx, &L.P_ci, P_ci, (size_t)nnzP));
-        KCHK(dev_upload_raw(ctx, &L.P_v, P_v, (size_t)nnzP));
         KCHK(dev_upload_raw(ctx, &L.R_rp, R_rp, (size_t)n_coarse + 1));
         KCHK(dev_upload_raw(ctx, &L.R_ci, R_ci, (size_t)nnzR));
-        KCHK(dev_upload_raw(ctx, &L.R_v, R_v, (size_t)nnzR));
+        if (ctx->amg_fp32) {
+            std::vector<float> tp(P_v, P_v + nnzP), tr(R_v, R_v + nnzR);
+            KCHK(dev_upload(ctx, &L.P_vf, tp));
+            KCHK(dev_upload(ctx, &L.R_vf, tr));
+        } else {
+            KCHK(dev_upload_raw(ctx, &L.P_v, P_v, (size_t)nnzP));
+            KCHK(dev_upload_raw(ctx, &L.R_v, R_v, (size_t)nnzR));
+        }
         L.P_lanes = pick_lanes((double)nnzP / n_rows);
         L.R_lanes = pick_lanes((double)nnzR / n_coarse);
     }
@@ -1957,18 +2007,34 @@ int knp_set_level_comm(knp_ctx* ctx, knp_level_comm_fn fn) {
     ctx->level_comm = fn;
     return KNP_OK;
 }
+int knp_amg_set_precision(knp_ctx* ctx, int32_t fp32_storage) {
+    CHECK_CTX(ctx);
+    ctx->amg_fp32 = fp32_storage ? 1 : 0;   // takes effect for hierarchies uploaded afterwards
+    return KNP_OK;
+}
 int knp_amg_use_native_level0(knp_ctx* ctx, int32_t hier, int32_t mode) {
     CHECK_CTX(ctx);
     if (hier < 0 || hier >= KNP_MAX_HIER || mode < 0 || mode > 3) { ctx->err = "bad arguments"; return KNP_E_ARG; }
     if (mode && !ctx->have_P) { ctx->err = "P not assembled"; return KNP_E_STATE; }
     ctx->hier[hier].native0 = mode;
+    if (mode && ctx->amg_fp32) {   // fp32 shadow of the pair-major P for the level-0 node kernels
+        const int64_t n = 4 * ctx->n_pairs;
+        if (!ctx->d_p_vals_f) HIPCHK(hipMalloc((void**)&ctx->d_p_vals_f, std::max<int64_t>(n, 1) * sizeof(float)));
+        hipLaunchKernelGGL(k_to_float, dim3(std::min<int64_t>(nblocks(n), 4096)), dim3(NT), 0, ctx->stream, n, ctx->d_p_vals, ctx->d_p_vals_f);
+        HIPCHK(hipGetLastError());
+    } else if (!ctx->amg_fp32) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        dev_free(ctx->d_p_vals_f);
+    }
     return KNP_OK;
 }
 int knp_amg_set_coarse(knp_ctx* ctx, int32_t hier, int32_t n, const double* inv) {
     CHECK_CTX(ctx);
     if (hier < 0 || hier >= KNP_MAX_HIER || n <= 0 || !inv) return KNP_E_ARG;
     KnpAmgHier& H = ctx->hier[hier];
-    dev_free(H.cinv);
+    dev_free(H.cinv); dev_free(H.cinv_f);
+    // the dense coarse inverse always stays fp64: the coarse potential block is nearly singular (cond ~1e8), so
+    // its inverse has entries that cancel to many digits and fp32 rounding would destroy the product
     KCHK(dev_upload_raw(ctx, &H.cinv, inv, (size_t)n * n));
     H.nc = n;
     return KNP_OK;
@@ -1993,9 +2059,9 @@ static void amg_smooth(knp_ctx* ctx, KnpAmgHier& H, int l, const double* b, doub
         if (native0)
             launch_pnode<0>(st, H.native0 - 1, ctx->spmv_group > 0 ? ctx->spmv_group : 8, ctx->g.n_nodes_owned,
                             L.dist ? ctx->g.n_nodes : ctx->g.n_nodes_owned, ctx->d_pair_ptr,
-                            ctx->d_pair_col, ctx->d_p_vals, L.inv_diag, b, xin, c1, c2, L.d, out);
+                            ctx->d_pair_col, ctx->d_p_vals, ctx->d_p_vals_f, L.inv_diag, b, xin, c1, c2, L.d, out);
         else
-            launch_cheby(st, L.A_lanes, L.n, L.A_rp, L.A_ci, L.A_v, L.inv_diag, b, xin, c1, c2, L.d, out);
+            launch_cheby(st, L.A_lanes, L.n, L.A_rp, L.A_ci, L.A_v, L.A_vf, L.inv_diag, b, xin, c1, c2, L.d, out);
     };
     if (zero_guess) {
         hipLaunchKernelGGL(k_cheby_first, dim3(std::min(nblocks(L.n), 2048)), dim3(NT), 0, st, L.n, 1.0 / theta, L.inv_diag, b, L.d, *cur);
@@ -2035,7 +2101,10 @@ static double* amg_vcycle(knp_ctx* ctx, KnpAmgHier& H, int l, const double* b, d
     double* bufA = want ? want : L.x;
     double* bufB = L.r2;
     if (last && H.nc > 0) {
-        hipLaunchKernelGGL(k_dense_matvec, dim3(nblocks((int64_t)H.nc * 64)), dim3(NT), 0, st, H.nc, H.cinv, b, bufA);
+        if (H.cinv_f)
+            hipLaunchKernelGGL((k_dense_matvec<float>), dim3(nblocks((int64_t)H.nc * 64)), dim3(NT), 0, st, H.nc, H.cinv_f, b, bufA);
+        else
+            hipLaunchKernelGGL((k_dense_matvec<double>), dim3(nblocks((int64_t)H.nc * 64)), dim3(NT), 0, st, H.nc, H.cinv, b, bufA);
         return bufA;
     }
     const int flips = amg_flips(H, last);
@@ -2057,10 +2126,10 @@ static double* amg_vcycle(knp_ctx* ctx, KnpAmgHier& H, int l, const double* b, d
     if (l == 0 && H.native0 > 0)
         launch_pnode<1>(st, H.native0 - 1, ctx->spmv_group > 0 ? ctx->spmv_group : 8, ctx->g.n_nodes_owned,
                         L.dist ? ctx->g.n_nodes : ctx->g.n_nodes_owned, ctx->d_pair_ptr,
-                        ctx->d_pair_col, ctx->d_p_vals, L.inv_diag, b, cur, 0.0, 0.0, L.d, L.r);
+                        ctx->d_pair_col, ctx->d_p_vals, ctx->d_p_vals_f, L.inv_diag, b, cur, 0.0, 0.0, L.d, L.r);
     else
-        launch_spmv<1>(st, L.A_lanes, L.n, L.A_rp, L.A_ci, L.A_v, cur, b, L.r);
-    launch_spmv<0>(st, L.R_lanes, nc, L.R_rp, L.R_ci, L.R_v, L.r, nullptr, C.b);
+        launch_spmv_mp<1>(st, L.A_lanes, L.n, L.A_rp, L.A_ci, L.A_v, L.A_vf, cur, b, L.r);
+    launch_spmv_mp<0>(st, L.R_lanes, nc, L.R_rp, L.R_ci, L.R_v, L.R_vf, L.r, nullptr, C.b);
     if (ctx->level_comm) {
         if (L.repl_n > 0) (void)ctx->level_comm(ctx->comm_user, hidx, l, 2, C.b);           // replicate the coarse rhs
         else if (C.dist) (void)ctx->level_comm(ctx->comm_user, hidx, l + 1, 1, C.b);        // ghost rows -> owners
@@ -2068,7 +2137,7 @@ static double* amg_vcycle(knp_ctx* ctx, KnpAmgHier& H, int l, const double* b, d
     double* xc = amg_vcycle(ctx, H, l + 1, C.b, nullptr);
     if (C.dist && ctx->level_comm && L.repl_n == 0) (void)ctx->level_comm(ctx->comm_user, hidx, l + 1, 0, xc);
     // x += P x_c (fused)
-    launch_spmv<2>(st, L.P_lanes, L.n, L.P_rp, L.P_ci, L.P_v, xc, nullptr, cur);
+    launch_spmv_mp<2>(st, L.P_lanes, L.n, L.P_rp, L.P_ci, L.P_v, L.P_vf, xc, nullptr, cur);
     for (int sw = 0; sw < H.post; ++sw) amg_smooth(ctx, H, l, b, &cur, bufA, bufB, false);
     return cur;
 }

@@ -126,3 +126,26 @@ def mms_config(dim=2, N=8, dt=1e-5, steps=1, rtol=1e-12):
             "solver": {"direct": False,
                        "ksp_settings": {"ksp_rtol": rtol, "ksp_type": "gmres", "pc_type": "hypre", "ksp_max_it": 2000},
                        "output": {"save_xdmf": False, "save_cpoints": False, "save_pngs": False, "save_dat": False}}}
+
+
+def fp32_stored(h):
+    """The hierarchy as the library holds it with ``amg_fp32`` (default): level, transfer and coarse-inverse
+    VALUES rounded to fp32 (diagonals, vectors, arithmetic and the dense coarse inverse stay fp64)."""
+    import copy
+    import numpy as np
+
+    def rnd(M):
+        if M is None:
+            return None
+        M = M.copy()
+        if hasattr(M, "data"):
+            M.data = M.data.astype(np.float32).astype(np.float64)
+            return M
+        return M.astype(np.float32).astype(np.float64)
+    out = copy.copy(h)
+    out.levels = []
+    for lv in h.levels:
+        l2 = copy.copy(lv)
+        l2.A, l2.P, l2.R = rnd(lv.A), rnd(lv.P), rnd(lv.R)
+        out.levels.append(l2)
+    return out

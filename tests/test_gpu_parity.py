@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from parity_utils import ci_config, make_oracle, make_problem, run_native, run_oracle
+from parity_utils import ci_config, fp32_stored, make_oracle, make_problem, run_native, run_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -166,15 +166,18 @@ def test_two_steps_match_oracle(pc):
         assert abs(ne - oe) <= 1e-4 * oe
 
 
+@pytest.mark.parametrize("fp32", [True, False])
 @pytest.mark.parametrize("N,kind,steps", [(32, "square", 3), (8, "cube", 2)])
-def test_gmres_amg_iterates_match_oracle_gmres(N, kind, steps):
+def test_gmres_amg_iterates_match_oracle_gmres(N, kind, steps, fp32):
     """Same algorithm on both sides: the oracle's PETSc-style GMRES(30) with the NumPy V-cycle applied to the
-    *same* hierarchy data must take the same number of iterations and land on the same iterate."""
+    *same* hierarchy data must take the same number of iterations and land on the same iterate.  With the
+    default mixed-precision storage the oracle gets the same fp32-rounded operator values."""
     import knpemi_oracle as K
     cfg = ci_config(N=N, steps=steps, rtol=1e-9, kind=kind)
     cfg["solver"]["ksp_settings"]["amg_coarse_size"] = 200      # force a real multilevel cycle on this small mesh
+    cfg["solver"]["ksp_settings"]["amg_fp32"] = fp32
     s = run_native(cfg)
-    h = s.hierarchy
+    h = fp32_stored(s.hierarchy) if fp32 else s.hierarchy
     assert len(h.levels) >= 2
     o = make_oracle(N, kind)
     xo, its = o.run(steps, solver="gmres", rtol=1e-9,
@@ -185,15 +188,19 @@ def test_gmres_amg_iterates_match_oracle_gmres(N, kind, steps):
         assert np.max(np.abs(x[f::4] - xo[f::4])) <= 1e-9 * np.max(np.abs(xo[f::4])), f
 
 
+@pytest.mark.parametrize("fp32", [True, False])
 @pytest.mark.parametrize("N,kind,steps", [(32, "square", 3), (8, "cube", 2)])
-def test_btcc_iterates_match_oracle(N, kind, steps):
+def test_btcc_iterates_match_oracle(N, kind, steps, fp32):
     """Block-triangular preconditioner (pc_type btcc): same algorithm restated in NumPy on the same two
     hierarchies -> same iteration counts, same iterates; and it converges to the LU solution."""
     import knpemi_oracle as K
     cfg = ci_config(N=N, steps=steps, rtol=1e-9, kind=kind, pc="btcc")
     cfg["solver"]["ksp_settings"]["amg_coarse_size"] = 150
+    cfg["solver"]["ksp_settings"]["amg_fp32"] = fp32
     s = run_native(cfg)
     hk, hp = s.hierarchies
+    if fp32:
+        hk, hp = fp32_stored(hk), fp32_stored(hp)
     assert len(hk.levels) >= 2 and len(hp.levels) >= 2
     o = make_oracle(N, kind)
     xo, its = o.run(steps, solver="gmres", rtol=1e-9,
