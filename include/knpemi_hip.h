@@ -154,6 +154,38 @@ int knp_set_stream(knp_ctx* ctx, void* hip_stream);
 int knp_set_comm(knp_ctx* ctx, knp_halo_fn halo, knp_allreduce_fn allreduce, void* user);
 int knp_set_level_comm(knp_ctx* ctx, knp_level_comm_fn fn);
 
+/* ---- native peer-to-peer exchange (multi-GPU, optional; replaces the hooks above once attached) ----
+ * Ghost values and reduction partials are written by a pack kernel straight into the neighbour's mailbox (uncached device
+ * memory mapped over hipIpc: xGMI stores between GPUs) and announced by a sequence flag; the consuming kernel waits on the
+ * flag.  No host round trip, no library call per exchange.  The rendezvous (who are my peers, their IPC handles, where
+ * my data lands in their mailbox) is done by the caller with whatever it has (torch.distributed, MPI):
+ *   knp_p2p_init            once per ctx
+ *   knp_p2p_plan_create     allocates this rank's mailbox of one plan, returns its 64-byte IPC handle
+ *   knp_p2p_plan_connect    maps the peers' mailboxes; halo plans also get the index lists and the peers' offsets
+ *   knp_p2p_attach          binds a connected plan to the fine halo, a level halo, a level's replicated all-reduce
+ *                           or the reduction slots
+ * All four are collective in the sense that every rank must make the same sequence of calls.  A wait that exceeds
+ * the timeout sets an error that the next knp_gmres_solve / knp_p2p_test_* reports (KNP_E_STATE). */
+#define KNP_P2P_HALO 0
+#define KNP_P2P_ALLREDUCE 1
+#define KNP_P2P_ATTACH_FINE_HALO 0
+#define KNP_P2P_ATTACH_LEVEL_HALO 1
+#define KNP_P2P_ATTACH_LEVEL_REPL 2
+#define KNP_P2P_ATTACH_SLOTS 3
+int knp_p2p_init(knp_ctx* ctx, int32_t rank, int32_t size, double timeout_seconds);
+int knp_p2p_shutdown(knp_ctx* ctx);   /* drop every plan and return to the hooks (all ranks together) */
+int knp_p2p_plan_create(knp_ctx* ctx, int32_t kind, int64_t n_fwd /* halo: ghost count | all-reduce: max length */,
+                        int64_t n_rev /* halo: total send count */, int32_t* plan_out, void* ipc_handle_out /* host [64] */);
+int knp_p2p_plan_connect(knp_ctx* ctx, int32_t plan, const void* handles /* host [size*64], one per rank */,
+                         int32_t n_peers, const int32_t* peer_rank /* host, ascending */,
+                         const int64_t* send_ptr /* host [n_peers+1] */, const int32_t* send_idx /* host: owned entries each peer needs */,
+                         const int64_t* remote_fwd_off /* host [n_peers]: where my values start in the peer's ghost list */,
+                         const int64_t* recv_ptr /* host [n_peers+1] */, const int32_t* recv_idx /* host: my ghost entries per peer */,
+                         const int64_t* remote_rev_off /* host [n_peers]: where my ghost copies start in the peer's send list */);
+int knp_p2p_attach(knp_ctx* ctx, int32_t what, int32_t hier, int32_t level, int32_t plan /* -1 detaches */);
+int knp_p2p_test_halo(knp_ctx* ctx, int32_t plan, double* x /* device */, int32_t reverse);
+int knp_p2p_test_allreduce(knp_ctx* ctx, int32_t plan, double* v /* device */, int32_t n);
+
 /* ---- description ---- */
 int knp_get_sizes(const knp_ctx* ctx, int64_t* sizes /* host [KNP_SZ_COUNT] */);
 int knp_get_layout(const knp_ctx* ctx, int32_t* node_i, int32_t* node_e /* host [n_vertices] each */);

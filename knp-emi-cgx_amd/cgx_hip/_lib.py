@@ -89,6 +89,15 @@ SIGNATURES = {
     "knp_amg_set_coarse": (C.c_int, [vp, C.c_int32, C.c_int32, f64p]),
     "knp_amg_use_native_level0": (C.c_int, [vp, C.c_int32, C.c_int32]),
     "knp_amg_set_precision": (C.c_int, [vp, C.c_int32]),
+    "knp_p2p_init": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_double]),
+    "knp_p2p_shutdown": (C.c_int, [vp]),
+    "knp_p2p_plan_create": (C.c_int, [vp, C.c_int32, C.c_int64, C.c_int64, C.POINTER(C.c_int32), vp]),
+    "knp_p2p_plan_connect": (C.c_int, [vp, C.c_int32, vp, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64),
+                                      C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+                                      C.POINTER(C.c_int64)]),
+    "knp_p2p_attach": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "knp_p2p_test_halo": (C.c_int, [vp, C.c_int32, vp, C.c_int32]),
+    "knp_p2p_test_allreduce": (C.c_int, [vp, C.c_int32, vp, C.c_int32]),
     "knp_gmres_solve": (C.c_int, [vp, vp, vp, C.c_double, C.c_double, C.c_int32, C.c_int32, i32p, f64p, i32p]),
     "knp_pack": (C.c_int, [vp, C.POINTER(FieldsOut), vp]),
     "knp_unpack": (C.c_int, [vp, vp, C.POINTER(FieldsOut)]),

@@ -3,6 +3,7 @@ back the block vectors.  Everything numerical goes through the C ABI (include/kn
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -103,6 +104,7 @@ class Backend:
             self.check(self.lib.knp_set_comm(self.ctx, self._halo_cb, self._ar_cb, None))
             self._lc_cb = _lib.LEVEL_COMM_FN(guarded(self._level_comm))
             self.check(self.lib.knp_set_level_comm(self.ctx, self._lc_cb))
+            self.p2p_setup()
         if getattr(problem, "programs", None):
             self.upload_programs()
         self.setup_deflation()
@@ -196,6 +198,142 @@ class Backend:
             h.forward(x)
         else:
             h.reverse_add(x)
+
+    # ---- native peer-to-peer exchange (csrc/knp_p2p.hip): rendezvous over torch.distributed, data path in the library
+    P2P_FINE, P2P_LEVEL_HALO, P2P_LEVEL_REPL, P2P_SLOTS = 0, 1, 2, 3
+
+    def _all_ok(self, ok):
+        return all(self.p.comm.all_gather_object(bool(ok)))
+
+    def p2p_setup(self):
+        """Enable the in-library exchange for the fine halo and the reduction slots.  Every step is collective and
+        ends with a self-test against the torch.distributed path; any failure on any rank leaves ALL ranks on the
+        hook path (KNP_COMM=hooks forces that)."""
+        comm = self.p.comm
+        self.p2p_on = False
+        self._p2p_plans = {}
+        if comm.size < 2 or comm.size > 16 or torch.device(self.device).type != "cuda":
+            return False
+        if os.environ.get("KNP_COMM", "p2p") != "p2p":
+            return False
+        rc = self.lib.knp_p2p_init(self.ctx, comm.rank, comm.size, float(os.environ.get("KNP_P2P_TIMEOUT", "30")))
+        if not self._all_ok(rc == 0):
+            self.lib.knp_p2p_shutdown(self.ctx)
+            return False
+        self.p2p_on = True
+        self.halo._h.n_own, self.halo._h.n_loc = int(self.n_dof_owned), int(self.n_dof_local)
+        slots = self._p2p_allreduce_plan(64)
+        fine = self._p2p_halo_plan(self.halo._h) if slots is not None else None
+        if slots is None or fine is None:
+            self.p2p_on = False
+            self.lib.knp_p2p_shutdown(self.ctx)
+            if comm.rank == 0:
+                print("native p2p exchange unavailable; using the torch.distributed hooks", flush=True)
+            return False
+        self.check(self.lib.knp_p2p_attach(self.ctx, self.P2P_SLOTS, 0, 0, slots))
+        self.check(self.lib.knp_p2p_attach(self.ctx, self.P2P_FINE, 0, 0, fine))
+        return True
+
+    def _p2p_allreduce_plan(self, n_max):
+        comm = self.p.comm
+        handle = (C.c_char * 64)()
+        plan = C.c_int32(-1)
+        rc = self.lib.knp_p2p_plan_create(self.ctx, 1, int(n_max), 0, C.byref(plan), handle)
+        info = comm.all_gather_object((rc, bytes(handle.raw)))
+        if any(i[0] != 0 for i in info):
+            return None
+        handles = b"".join(i[1] for i in info)
+        rc = self.lib.knp_p2p_plan_connect(self.ctx, plan.value, handles, 0, None, None, None, None, None, None, None)
+        if not self._all_ok(rc == 0):
+            return None
+        # self-test: sum of rank-dependent vectors, identical bits on every rank
+        n = min(int(n_max), 64)
+        v = torch.arange(n, dtype=torch.float64, device=self.device) * 0.5 + (comm.rank + 1)
+        ref = torch.arange(n, dtype=torch.float64, device=self.device) * 0.5 * comm.size + comm.size * (comm.size + 1) / 2
+        rc = self.lib.knp_p2p_test_allreduce(self.ctx, plan.value, C.c_void_p(v.data_ptr()), n)
+        good = rc == 0 and bool(torch.equal(v, ref))
+        return plan.value if self._all_ok(good) else None
+
+    def _p2p_halo_plan(self, h):
+        """Plan for one LevelHalo (cached: the same halo object may serve several attachments)."""
+        if id(h) in self._p2p_plans:
+            return self._p2p_plans[id(h)]
+        comm = self.p.comm
+        me = comm.rank
+        peers = sorted(int(r) for r in h.peers)
+        n_send = {r: int(len(h.send_idx[r])) if r in h.send_idx else 0 for r in peers}
+        n_recv = {r: int(len(h.recv_idx[r])) if r in h.recv_idx else 0 for r in peers}
+        send_ptr = np.concatenate([[0], np.cumsum([n_send[r] for r in peers])]).astype(np.int64)
+        recv_ptr = np.concatenate([[0], np.cumsum([n_recv[r] for r in peers])]).astype(np.int64)
+        n_fwd, n_rev = int(recv_ptr[-1]), int(send_ptr[-1])
+        handle = (C.c_char * 64)()
+        plan = C.c_int32(-1)
+        rc = self.lib.knp_p2p_plan_create(self.ctx, 0, n_fwd, n_rev, C.byref(plan), handle) if len(peers) <= 16 else -1
+        mine = {"rc": rc, "handle": bytes(handle.raw), "n_fwd": n_fwd, "n_rev": n_rev,
+                "recv_off": {r: int(recv_ptr[j]) for j, r in enumerate(peers)},
+                "send_off": {r: int(send_ptr[j]) for j, r in enumerate(peers)}}
+        info = comm.all_gather_object(mine)
+        if any(i["rc"] != 0 for i in info):
+            self._p2p_plans[id(h)] = None
+            return None
+        handles = b"".join(i["handle"] for i in info)
+        symmetric = all(me in info[r]["recv_off"] for r in peers)
+        fwd_off = np.zeros(2 * len(peers), dtype=np.int64)
+        rev_off = np.zeros(2 * len(peers), dtype=np.int64)
+        if symmetric:
+            for j, r in enumerate(peers):
+                B = info[r]
+                for par in (0, 1):
+                    fwd_off[2 * j + par] = par * B["n_fwd"] + B["recv_off"][me]
+                    rev_off[2 * j + par] = 2 * B["n_fwd"] + par * B["n_rev"] + B["send_off"][me]
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        send_idx = i32(h.send_all.cpu().numpy())
+        recv_idx = i32(h.recv_all.cpu().numpy())
+        pr = i32(peers)
+        p32, p64 = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+        rc = -1
+        if symmetric:
+            rc = self.lib.knp_p2p_plan_connect(self.ctx, plan.value, handles, len(peers), pr.ctypes.data_as(p32),
+                                               send_ptr.ctypes.data_as(p64), send_idx.ctypes.data_as(p32), fwd_off.ctypes.data_as(p64),
+                                               recv_ptr.ctypes.data_as(p64), recv_idx.ctypes.data_as(p32), rev_off.ctypes.data_as(p64))
+        if not self._all_ok(rc == 0):
+            self._p2p_plans[id(h)] = None
+            return None
+        # self-test against the torch.distributed exchange of the same halo (forward twice: both mailbox parities)
+        good = True
+        for rep in range(2):
+            x = torch.zeros(h.n_loc, dtype=torch.float64, device=self.device)
+            x[:h.n_own] = torch.arange(h.n_own, dtype=torch.float64, device=self.device) + 1e6 * (me + 1) + rep
+            y = x.clone()
+            h.forward(y)
+            rc = self.lib.knp_p2p_test_halo(self.ctx, plan.value, C.c_void_p(x.data_ptr()), 0)
+            good = good and rc == 0 and bool(torch.equal(x, y))
+            x = torch.sin(torch.arange(h.n_loc, dtype=torch.float64, device=self.device) * (0.37 + rep) + me)
+            y = x.clone()
+            h.reverse_add(y)
+            rc = self.lib.knp_p2p_test_halo(self.ctx, plan.value, C.c_void_p(x.data_ptr()), 1)
+            good = good and rc == 0 and bool(torch.allclose(x, y, rtol=1e-13, atol=1e-13))
+        ok = self._all_ok(good)
+        self._p2p_plans[id(h)] = plan.value if ok else None
+        self._p2p_keep = getattr(self, "_p2p_keep", []) + [send_idx, recv_idx]
+        return self._p2p_plans[id(h)]
+
+    def p2p_attach_level(self, hier, level, halo, repl_n=0):
+        """Bind the native exchange to one level of a distributed hierarchy (collective; falls back to the hook)."""
+        if not getattr(self, "p2p_on", False):
+            return
+        plan = self._p2p_halo_plan(halo)
+        rp = self._p2p_allreduce_plan(int(repl_n)) if (repl_n and plan is not None) else None
+        if plan is None or (repl_n and rp is None):
+            # a failed self-test may have latched a timeout: drop the native path everywhere (same decision on all ranks)
+            self.p2p_on = False
+            self.lib.knp_p2p_shutdown(self.ctx)
+            if self.p.comm.rank == 0:
+                print("native p2p exchange failed its self-test on a hierarchy level; using the torch.distributed hooks", flush=True)
+            return
+        self.check(self.lib.knp_p2p_attach(self.ctx, self.P2P_LEVEL_HALO, hier, level, plan))
+        if repl_n:
+            self.check(self.lib.knp_p2p_attach(self.ctx, self.P2P_LEVEL_REPL, hier, level, rp))
 
     def dof_level_halo(self):
         """LevelHalo of the fine DoF vector layout (level 0 of a distributed hierarchy)."""

@@ -198,6 +198,7 @@ class SolverKNPEMI:
                 be.level_halos[(index, l)] = L.halo
                 if L.replicated:
                     be.level_repl[(index, l)] = int(L.repl_n)
+                be.p2p_attach_level(index, l, L.halo, int(L.repl_n) if L.replicated else 0)
             self.hierarchies.append((levels, tail))
             self.print(f"distributed AMG hierarchy {index}: {dist_amg.describe(levels, tail, self.comm)}")
         self.hierarchy = self.hierarchies[0]

@@ -56,6 +56,38 @@ struct KnpProgram {
     double* d_consts = nullptr;
 };
 
+struct knp_ctx;
+// ---- native peer-to-peer communication (knp_p2p.hip) ----
+#define KNP_P2P_MAXPEERS 16
+struct KnpP2PPlan {
+    int kind = 0;                       // 0 halo, 1 all-reduce
+    int64_t n_fwd = 0, n_rev = 0;       // halo: ghost count / send total; all-reduce: n_max / unused
+    char* box = nullptr;                // own mailbox: uncached device memory exported over IPC
+    size_t box_bytes = 0, hdr_bytes = 0;
+    std::vector<char*> peer_box;        // [size] mapped mailboxes of the other ranks (nullptr: not a peer; own rank: box)
+    int n_peers = 0;
+    int peer_rank[KNP_P2P_MAXPEERS];
+    int64_t send_ptr[KNP_P2P_MAXPEERS + 1], recv_ptr[KNP_P2P_MAXPEERS + 1];
+    std::vector<int64_t> remote_fwd_off, remote_rev_off;   // [2*n_peers]: element offset in the peer's data area per parity
+    int32_t *d_send_idx = nullptr, *d_recv_idx = nullptr;
+    unsigned int* d_counter = nullptr;  // "last block done" counters of the pack kernels
+    int64_t seq_fwd = 0, seq_rev = 0;   // message sequence numbers (identical on all ranks: calls are collective)
+    bool connected = false;
+};
+struct KnpP2P {
+    int rank = 0, size = 1;
+    int64_t timeout_ticks = 0;          // wall_clock64 ticks a wait may take before it is reported
+    int* h_err = nullptr;               // pinned, device-visible: bit 0 = a wait timed out
+    int* h_err_dev = nullptr;
+    int* d_err = nullptr;               // device twin: later waits give up at once after the first timeout
+    std::vector<KnpP2PPlan> plans;
+};
+int knp_p2p_halo_forward(knp_ctx* ctx, int plan, double* x);
+int knp_p2p_halo_reverse(knp_ctx* ctx, int plan, double* x);
+int knp_p2p_allreduce(knp_ctx* ctx, int plan, double* v, int n, double* mirror, int64_t* seq_dev, int64_t seq_val);
+int knp_p2p_check(knp_ctx* ctx);
+void knp_p2p_free(knp_ctx* ctx);
+
 struct KnpAmgLevel {
     int n = 0, n_coarse = 0;
     int n_loc = 0;   // local columns = owned + ghost (== n on one GPU)
@@ -64,6 +96,7 @@ struct KnpAmgLevel {
     int32_t *A_rp = nullptr, *A_ci = nullptr;
     double* A_v = nullptr;
     float *A_vf = nullptr, *P_vf = nullptr, *R_vf = nullptr;   // fp32 copies (mixed-precision preconditioner storage)
+    int p2p_halo = -1, p2p_repl = -1;   // native exchange plans of this level (-1: hook)
     double* inv_diag = nullptr;
     double lambda_max = 1.0;
     int32_t *P_rp = nullptr, *P_ci = nullptr;
@@ -155,7 +188,8 @@ struct knp_ctx {
     double* d_red = nullptr;     // [64] reduced values
     double* h_red = nullptr;     // pinned host mirror
     double* h_red_dev = nullptr; // device-visible address of h_red (zero-copy read-back)
-    double* mirror() const { return allreduce ? nullptr : h_red_dev; }
+    // reductions publish straight to pinned host memory, except on the hook path (its all-reduce result is fetched by a copy)
+    double* mirror() const { return (allreduce && p2p_red < 0) ? nullptr : h_red_dev; }
     int64_t phi_count_cached = -1;
     int64_t* h_seq = nullptr;        // pinned sequence word published by the last reduction kernel of a read-back
     int64_t* h_seq_dev = nullptr;
@@ -176,6 +210,12 @@ struct knp_ctx {
     knp_allreduce_fn allreduce = nullptr;
     knp_level_comm_fn level_comm = nullptr;
     void* comm_user = nullptr;
+    // native peer-to-peer exchange (knp_p2p.hip); plan indices, -1 = use the hooks above
+    KnpP2P* p2p = nullptr;
+    int p2p_fine = -1;   // halo of the fine DoF vector
+    int p2p_red = -1;    // all-reduce of the reduction slots
+    bool hook_allreduce() const { return allreduce && p2p_red < 0; }
+    int comm_rc = 0;     // first failure of a level exchange inside a preconditioner application
     // profiling
     int prof_on = 0;
     struct ProfRec { hipEvent_t a, b; int cls; };

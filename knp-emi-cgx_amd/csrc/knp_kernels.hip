@@ -1422,6 +1422,7 @@ int knp_create(knp_ctx** out, const knp_mesh_desc* mesh) {
 int knp_destroy(knp_ctx* ctx) {
     if (!ctx) return KNP_OK;
     (void)hipDeviceSynchronize();
+    knp_p2p_free(ctx);
     for (auto& r : ctx->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     dev_free(ctx->d_cells); dev_free(ctx->d_cell_side); dev_free(ctx->d_coords);
     dev_free(ctx->d_node_vertex); dev_free(ctx->d_node_side); dev_free(ctx->d_node_i); dev_free(ctx->d_node_e);
@@ -1772,6 +1773,9 @@ int knp_assemble_rhs(knp_ctx* ctx, const knp_fields* fields, double* b) {
 
 // ---- reductions: partial blocks -> d_red[slot], then (multi-GPU) all-reduce of a slot range ----
 static int allreduce_slots(knp_ctx* ctx, int slot0, int count) {
+    if (ctx->p2p_red >= 0)   // native exchange: the summing kernel also fills the pinned mirror and publishes the sequence word
+        return knp_p2p_allreduce(ctx, ctx->p2p_red, ctx->d_red + slot0, count, ctx->h_red_dev ? ctx->h_red_dev + slot0 : nullptr,
+                                 ctx->h_red_dev ? ctx->h_seq_dev : nullptr, ++ctx->seq_counter);
     if (ctx->allreduce) {
         int rc = ctx->allreduce(ctx->comm_user, ctx->d_red + slot0, count);
         if (rc != 0) { ctx->err = "allreduce hook failed"; return KNP_E_STATE; }
@@ -1779,6 +1783,7 @@ static int allreduce_slots(knp_ctx* ctx, int slot0, int count) {
     return KNP_OK;
 }
 static int halo_update(knp_ctx* ctx, double* x) {
+    if (ctx->p2p_fine >= 0) return knp_p2p_halo_forward(ctx, ctx->p2p_fine, x);
     if (ctx->halo) {
         int rc = ctx->halo(ctx->comm_user, x);
         if (rc != 0) { ctx->err = "halo hook failed"; return KNP_E_STATE; }
@@ -1792,8 +1797,13 @@ static int dot_to_slot(knp_ctx* ctx, const double* a, const double* b, int slot)
                        ctx->mirror() ? ctx->h_seq_dev : nullptr, ++ctx->seq_counter);
     return allreduce_slots(ctx, slot, 1);
 }
+static int read_slots_inner(knp_ctx* ctx, int slot0, int count, int64_t wait_seq);
 static int read_slots(knp_ctx* ctx, int slot0, int count, int64_t wait_seq = 0) {
-    if (ctx->allreduce || !ctx->h_red_dev) {  // reduced over ranks in d_red: fetch; else the kernel already wrote the mirror
+    KCHK(read_slots_inner(ctx, slot0, count, wait_seq));
+    return ctx->p2p ? knp_p2p_check(ctx) : KNP_OK;   // a peer that never arrived: stop here, not after max_it iterations
+}
+static int read_slots_inner(knp_ctx* ctx, int slot0, int count, int64_t wait_seq) {
+    if (ctx->hook_allreduce() || !ctx->h_red_dev) {  // reduced over ranks in d_red: fetch; else the kernel already wrote the mirror
         HIPCHK(hipMemcpyAsync(ctx->h_red + slot0, ctx->d_red + slot0, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         return KNP_OK;
@@ -2040,6 +2050,23 @@ int knp_amg_set_coarse(knp_ctx* ctx, int32_t hier, int32_t n, const double* inv)
     return KNP_OK;
 }
 
+// exchange step of a distributed hierarchy: op 0 forward halo of a level-l vector, op 1 reverse halo (ghost rows added
+// to their owners), op 2 SUM of the replicated coarse right-hand side built on level l.  Native plans when attached,
+// the caller's hook otherwise.  Errors are latched in ctx->comm_rc (checked at the end of the solve).
+static void level_exchange(knp_ctx* ctx, int hidx, int l, int op, double* vec) {
+    KnpAmgLevel& L = ctx->hier[hidx].lv[l];
+    int rc = KNP_OK;
+    if (op == 2 && L.p2p_repl >= 0) rc = knp_p2p_allreduce(ctx, L.p2p_repl, vec, L.repl_n, nullptr, nullptr, 0);
+    else if (op == 0 && L.p2p_halo >= 0) rc = knp_p2p_halo_forward(ctx, L.p2p_halo, vec);
+    else if (op == 1 && L.p2p_halo >= 0) rc = knp_p2p_halo_reverse(ctx, L.p2p_halo, vec);
+    else if (ctx->level_comm) rc = ctx->level_comm(ctx->comm_user, hidx, l, op, vec) != 0 ? KNP_E_STATE : KNP_OK;
+    if (rc != KNP_OK && ctx->comm_rc == KNP_OK) {
+        ctx->comm_rc = rc;
+        if (ctx->err.empty() || rc == KNP_E_STATE) ctx->err = "level exchange failed (hierarchy " + std::to_string(hidx) + ", level " + std::to_string(l) + "): " + ctx->err;
+    }
+}
+static inline bool level_comm_on(const knp_ctx* ctx) { return ctx->level_comm != nullptr || ctx->p2p != nullptr; }
+
 // Chebyshev smoothing sweep of A x = b on one level with ping-pong buffers.  On entry the iterate is in
 // *cur (ignored when zero_guess); the sweep alternates between bufA and bufB and leaves *cur pointing at
 // the buffer that holds the result.
@@ -2055,7 +2082,7 @@ static void amg_smooth(knp_ctx* ctx, KnpAmgHier& H, int l, const double* b, doub
     const bool native0 = (l == 0) && H.native0 > 0;
     const int hidx = (int)(&H - ctx->hier);
     auto step = [&](double* xin, double c1, double c2, double* out) {
-        if (L.dist && ctx->level_comm) (void)ctx->level_comm(ctx->comm_user, hidx, l, 0, xin);
+        if (L.dist && level_comm_on(ctx)) level_exchange(ctx, hidx, l, 0, xin);
         if (native0)
             launch_pnode<0>(st, H.native0 - 1, ctx->spmv_group > 0 ? ctx->spmv_group : 8, ctx->g.n_nodes_owned,
                             L.dist ? ctx->g.n_nodes : ctx->g.n_nodes_owned, ctx->d_pair_ptr,
@@ -2122,7 +2149,7 @@ static double* amg_vcycle(knp_ctx* ctx, KnpAmgHier& H, int l, const double* b, d
     if (zero) hipLaunchKernelGGL(k_fill, dim3(std::min(nblocks(L.n), 2048)), dim3(NT), 0, st, L.n, 0.0, cur);
     // r = b - A x ; b_c = R r
     const int hidx = (int)(&H - ctx->hier);
-    if (L.dist && ctx->level_comm) (void)ctx->level_comm(ctx->comm_user, hidx, l, 0, cur);
+    if (L.dist && level_comm_on(ctx)) level_exchange(ctx, hidx, l, 0, cur);
     if (l == 0 && H.native0 > 0)
         launch_pnode<1>(st, H.native0 - 1, ctx->spmv_group > 0 ? ctx->spmv_group : 8, ctx->g.n_nodes_owned,
                         L.dist ? ctx->g.n_nodes : ctx->g.n_nodes_owned, ctx->d_pair_ptr,
@@ -2130,12 +2157,12 @@ static double* amg_vcycle(knp_ctx* ctx, KnpAmgHier& H, int l, const double* b, d
     else
         launch_spmv_mp<1>(st, L.A_lanes, L.n, L.A_rp, L.A_ci, L.A_v, L.A_vf, cur, b, L.r);
     launch_spmv_mp<0>(st, L.R_lanes, nc, L.R_rp, L.R_ci, L.R_v, L.R_vf, L.r, nullptr, C.b);
-    if (ctx->level_comm) {
-        if (L.repl_n > 0) (void)ctx->level_comm(ctx->comm_user, hidx, l, 2, C.b);           // replicate the coarse rhs
-        else if (C.dist) (void)ctx->level_comm(ctx->comm_user, hidx, l + 1, 1, C.b);        // ghost rows -> owners
+    if (level_comm_on(ctx)) {
+        if (L.repl_n > 0) level_exchange(ctx, hidx, l, 2, C.b);           // replicate the coarse rhs
+        else if (C.dist) level_exchange(ctx, hidx, l + 1, 1, C.b);        // ghost rows -> owners
     }
     double* xc = amg_vcycle(ctx, H, l + 1, C.b, nullptr);
-    if (C.dist && ctx->level_comm && L.repl_n == 0) (void)ctx->level_comm(ctx->comm_user, hidx, l + 1, 0, xc);
+    if (C.dist && level_comm_on(ctx) && L.repl_n == 0) level_exchange(ctx, hidx, l + 1, 0, xc);
     // x += P x_c (fused)
     launch_spmv_mp<2>(st, L.P_lanes, L.n, L.P_rp, L.P_ci, L.P_v, L.P_vf, xc, nullptr, cur);
     for (int sw = 0; sw < H.post; ++sw) amg_smooth(ctx, H, l, b, &cur, bufA, bufB, false);
@@ -2391,6 +2418,11 @@ int knp_gmres_solve(knp_ctx* ctx, const double* b, double* x, double rtol, doubl
     *rnorm = res;
     KCHK(halo_update(ctx, x));
     HIPCHK(hipGetLastError());
+    if (ctx->p2p) {   // the final halo is two asynchronous kernels: make its outcome (and any timeout) known before returning
+        HIPCHK(hipStreamSynchronize(st));
+        KCHK(knp_p2p_check(ctx));
+    }
+    if (ctx->comm_rc != KNP_OK) { const int rc2 = ctx->comm_rc; ctx->comm_rc = KNP_OK; return rc2; }
     return KNP_OK;
 }
 

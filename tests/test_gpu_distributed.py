@@ -1,5 +1,6 @@
-"""Two ranks sharing the one GPU of the test box (gloo for the exchanges, staged through the host): runs
-the real library with its halo / all-reduce hooks and checks the partitioned solve against the oracle."""
+"""Several ranks sharing the one GPU of the test box: runs the real library on a partitioned mesh and checks the
+solve against the oracle, once with the native peer-to-peer exchange (mailboxes mapped over hipIpc; the rendezvous
+uses gloo) and once with the torch.distributed hooks (gloo, staged through the host)."""
 import os
 import socket
 import sys
@@ -20,8 +21,10 @@ def _free_port():
     return p
 
 
-def _worker(rank, size, port, q, rtol=1e-13, extra=None, N=16, kind="square", pc="hypre"):
+def _worker(rank, size, port, q, rtol=1e-13, extra=None, N=16, kind="square", pc="hypre", comm="p2p"):
     try:
+        os.environ["KNP_COMM"] = comm
+        os.environ.setdefault("KNP_P2P_TIMEOUT", "10")
         for p in (os.path.join(ROOT, "knp-emi-cgx_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
             sys.path.insert(0, p)
         os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -39,7 +42,8 @@ def _worker(rank, size, port, q, rtol=1e-13, extra=None, N=16, kind="square", pc
         lm = s.problem.local_mesh
         nvo = lm.n_vertices_owned
         phim = s.problem.phi_m_prev.numpy()
-        q.put((rank, "ok", ni, ne, lm.l2g[:nvo].copy(), phim[:nvo].copy(), list(s.iterations), s.backend.n_dof_global))
+        q.put((rank, "ok", ni, ne, lm.l2g[:nvo].copy(), phim[:nvo].copy(), list(s.iterations), s.backend.n_dof_global,
+               bool(getattr(s.backend, "p2p_on", False))))
         dist.barrier()
         dist.destroy_process_group()
     except Exception:      # noqa: BLE001
@@ -59,18 +63,20 @@ def _run(size, **kw):
         p.join(timeout=60)
     for r in res:
         assert r[1] == "ok", f"rank {r[0]}:\n{r[1]}"
+        assert r[8] == (kw.get("comm", "p2p") == "p2p"), "the requested exchange path is not the one that ran"
     return res
 
 
+@pytest.mark.parametrize("comm", ["p2p", "hooks"])
 @pytest.mark.parametrize("extra,N,kind,pc,max_its", [
     ({}, 32, "square", "hypre", 6),                                   # level 0 distributed, coarse levels replicated
     ({"amg_replicate_below": 60, "amg_coarse_size": 40}, 32, "square", "hypre", 6),   # two distributed levels
     ({"amg_coarse_size": 150}, 8, "cube", "btcc", 22),                # both hierarchies of the block-triangular PC
 ])
-def test_global_amg_keeps_single_gpu_iteration_counts(extra, N, kind, pc, max_its):
+def test_global_amg_keeps_single_gpu_iteration_counts(extra, N, kind, pc, max_its, comm):
     """The distributed hierarchy is a global preconditioner: iteration counts stay at the single-GPU level
     (per-GPU block-Jacobi AMG needs 6x more in 2D) and the solution matches the oracle."""
-    res = _run(2, rtol=1e-9, extra=extra, N=N, kind=kind, pc=pc)
+    res = _run(2, rtol=1e-9, extra=extra, N=N, kind=kind, pc=pc, comm=comm)
     from parity_utils import run_oracle
     o = run_oracle(N=N, steps=2, kind=kind)
     oi, oe = o.potential_norms()
@@ -79,19 +85,9 @@ def test_global_amg_keeps_single_gpu_iteration_counts(extra, N, kind, pc, max_it
         assert abs(r[2] - oi) <= 2e-6 * oi
 
 
-def test_two_ranks_one_gpu_match_oracle():
-    size = 2
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, size, port, q)) for r in range(size)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=300) for _ in range(size)]
-    for p in procs:
-        p.join(timeout=60)
-    for r in res:
-        assert r[1] == "ok", f"rank {r[0]}:\n{r[1]}"
+@pytest.mark.parametrize("size,comm", [(2, "p2p"), (2, "hooks"), (4, "p2p")])
+def test_ranks_on_one_gpu_match_oracle(size, comm):
+    res = _run(size, comm=comm)
     from parity_utils import run_oracle
     o = run_oracle(N=16, steps=2)
     oi, oe = o.potential_norms()
@@ -103,3 +99,57 @@ def test_two_ranks_one_gpu_match_oracle():
         phim[r[4]] = r[5]
     gam = (o.lay.node_i >= 0) & (o.lay.node_e >= 0)
     assert np.allclose(phim[gam], o.phi_m[gam], rtol=1e-6)
+
+
+def _timeout_worker(rank, size, port, q):
+    try:
+        for p in (os.path.join(ROOT, "knp-emi-cgx_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+            sys.path.insert(0, p)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ["KNP_COMM"] = "p2p"
+        os.environ["KNP_P2P_TIMEOUT"] = "2"
+        import ctypes as C
+        import time
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=size)
+        from parity_utils import ci_config, make_problem
+        p = make_problem(ci_config(N=8, steps=1))
+        be = p.create_backend()
+        assert be.p2p_on
+        plan = be._p2p_allreduce_plan(8)          # collective, self-tested
+        assert plan is not None
+        out = "skipped"
+        if rank == 0:                              # rank 1 never shows up for this exchange
+            v = torch.ones(8, dtype=torch.float64, device="cuda")
+            t0 = time.perf_counter()
+            rc = be.lib.knp_p2p_test_allreduce(be.ctx, plan, C.c_void_p(v.data_ptr()), 8)
+            out = (rc, time.perf_counter() - t0, be.lib.knp_last_error(be.ctx).decode())
+        dist.barrier()
+        q.put((rank, "ok", out))
+        dist.destroy_process_group()
+    except Exception:      # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+def test_p2p_wait_times_out_instead_of_hanging():
+    """A peer that never arrives must end in an error code after the timeout, not in a kernel that spins for ever."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_timeout_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict()
+    for _ in range(2):
+        r = q.get(timeout=300)
+        assert r[1] == "ok", f"rank {r[0]}:\n{r[1]}"
+        res[r[0]] = r[2]
+    for p in procs:
+        p.join(timeout=60)
+    rc, secs, msg = res[0]
+    assert rc != 0 and "timed out" in msg
+    assert 1.5 <= secs <= 20.0
