@@ -34,7 +34,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", type=str, default="square512", help="square<N> or cube<N> (per-GPU mesh)")
+    ap.add_argument("--workload", type=str, default="square512",
+                    help="square<N> | cube<N> (per-GPU mesh, weak scaling) | tissue<dim>d_<N>_<m> (lattice of m^dim cells, one tag "
+                         "per cell: the tissue surrogate of SURVEY 8d; the global mesh is partitioned over the ranks)")
     ap.add_argument("--pc", type=str, default="auto", help="auto (hypre-form AMG in 2D, btcc in 3D) | hypre | btcc | vbjacobi | none")
     ap.add_argument("--rtol", type=float, default=1e-9)
     ap.add_argument("--models", type=str, default="ci", help="ci (HH+ATP+cotransporters) | passive")
@@ -66,22 +68,32 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import re
-    from parity_utils import ci_config, make_problem
+    from parity_utils import ci_config, make_problem, tissue_config
     from cgx_hip import _lib
     from cgx_hip.parallel import stacked_cubes_local_mesh, stacked_squares_local_mesh
     from CGx.KNPEMI.KNPEMIx_solver import SolverKNPEMI
 
-    m = re.fullmatch(r"(square|cube)(\d+)", args.workload)
-    assert m, "workload must be square<N> or cube<N>"
-    kind, N = m.group(1), int(m.group(2))
-    if args.pc == "auto":
-        args.pc = "hypre" if kind == "square" else "btcc"
-    gen = stacked_squares_local_mesh if kind == "square" else stacked_cubes_local_mesh
-    lm = gen(N, world, rank, scale=1e-6)
-
     total_steps = args.warmup + args.steps
-    cfg = ci_config(N=N, steps=total_steps, rtol=args.rtol, pc=args.pc, kind=kind)
-    problem = make_problem(cfg, models=args.models, local_mesh=lm)
+    mt = re.fullmatch(r"tissue(\d)d_(\d+)_(\d+)", args.workload)
+    m = re.fullmatch(r"(square|cube)(\d+)", args.workload)
+    assert m or mt, "workload must be square<N>, cube<N> or tissue<dim>d_<N>_<m>"
+    if mt:
+        tdim, N, ncell = int(mt.group(1)), int(mt.group(2)), int(mt.group(3))
+        kind = "square" if tdim == 2 else "cube"
+        if args.pc == "auto":
+            args.pc = "hypre" if tdim == 2 else "btcc"
+        cfg = tissue_config(tdim, N, ncell, steps=total_steps, rtol=args.rtol, pc=args.pc, stimulus=(args.models == "ci"))
+        problem = make_problem(cfg, models=args.models)          # the problem partitions the global mesh itself
+        what = f"tissue surrogate: unit {kind} {N}^{tdim} with {ncell}^{tdim} cells (one tag each), over {world} GPU(s)"
+    else:
+        kind, N = m.group(1), int(m.group(2))
+        if args.pc == "auto":
+            args.pc = "hypre" if kind == "square" else "btcc"
+        gen = stacked_squares_local_mesh if kind == "square" else stacked_cubes_local_mesh
+        lm = gen(N, world, rank, scale=1e-6)
+        cfg = ci_config(N=N, steps=total_steps, rtol=args.rtol, pc=args.pc, kind=kind)
+        problem = make_problem(cfg, models=args.models, local_mesh=lm)
+        what = f"{world} x unit {kind} {N}^{2 if kind == 'square' else 3} (BASELINE configs[{1 if kind == 'square' else 2}])"
     problem.solver_config["view_ksp"] = False
     solver = SolverKNPEMI(problem, solver_config=problem.solver_config)
 
@@ -177,17 +189,17 @@ def main():
 
     # ---- CPU baseline: the oracle (NumPy/SciPy restatement, 1 core) on a bounded sample --------
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not mt:
         cpu = cpu_baseline(kind, N, args.models, args.rtol, args.cpu_steps, args.pc, solver)
 
     if rank == 0:
         out = {
             "metric": "MDoF/s per implicit timestep (assembly+GMRES)",
             "value": value, "unit": "MDoF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if (mt and world > 1) else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{world} x unit {kind} {N}^{2 if kind == 'square' else 3} (BASELINE configs[{1 if kind == 'square' else 2}]), "
-                                   f"3 ions, HH+ATP+cotransporters, GMRES(30)+{'AMG on block-diagonal P' if args.pc in ('hypre', 'amg') else args.pc}, rtol {args.rtol:g}",
+            "config": {"workload": f"{what}, "
+                                   f"3 ions, {'HH+ATP+cotransporters' if args.models == 'ci' else 'passive membrane'}, GMRES(30)+{'AMG on block-diagonal P' if args.pc in ('hypre', 'amg') else args.pc}, rtol {args.rtol:g}",
                        "n_dof": int(n_dof), "nnz": int(be.nnz_global), "mechanisms": args.models, "pc": args.pc,
                        "parallelism": f"dd{world}", "gmres_its_per_step": float(sum(its_all)) / max(len(its_all), 1),
                        "converged_all": bool(all(r > 0 for r in reasons)),

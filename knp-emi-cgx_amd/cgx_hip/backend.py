@@ -45,7 +45,8 @@ class Backend:
         side = np.ascontiguousarray(problem.cell_side, dtype=np.uint8)
         gamma = np.ascontiguousarray(lm.gamma, dtype=np.int32)
         tag_index = {t: k for k, t in enumerate(problem.gamma_tags)}
-        gprog = np.ascontiguousarray([tag_index[int(t)] for t in lm.gamma_tags], dtype=np.int32)
+        self.tag_program = dict(getattr(problem, "tag_program", None) or {k: k for k in tag_index.values()})
+        gprog = np.ascontiguousarray([self.tag_program[tag_index[int(t)]] for t in lm.gamma_tags], dtype=np.int32)
         qp = np.ascontiguousarray(problem.q_pts, dtype=np.float64)
         qw = np.ascontiguousarray(problem.q_w, dtype=np.float64)
         self._keep += [coords, cells, side, gamma, gprog, qp, qw]

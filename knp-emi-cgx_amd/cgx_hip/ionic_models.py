@@ -249,7 +249,14 @@ class HodgkinHuxley(IonicModel):
                     mask = mask * ufl.conditional(ufl.And(ufl.gt(x[d], float(range[i][0])), ufl.lt(x[d], float(range[i][1]))), 1.0, 0.0)
         stim_current = mask * p.g_syn_bar * exp_factor * (p.phi_m_prev - ion["E"])
         if p.scale_stimulus:
-            p.stimulus_area = p.integrate_over_membrane(mask, p.stimulus_tags)
+            # the reference integrates the mask over all stimulus tags once per membrane tag; the value only depends on
+            # the region, so tissue configs with hundreds of tags integrate once
+            key = (None if range is None else tuple(np.ravel(np.asarray(range, dtype=float)).tolist()),
+                   None if dir is None else tuple(np.ravel(dir).tolist()), tuple(p.stimulus_tags))
+            cache = p.__dict__.setdefault("_stimulus_area_cache", {})
+            if key not in cache:
+                cache[key] = p.integrate_over_membrane(mask, p.stimulus_tags)
+            p.stimulus_area = cache[key]
             p.print(f"Stimulus area on tag {p.stimulus_tags[0]}: {p.stimulus_area:0.6e} m^2")
             stim_current = stim_current * (1.0 / p.stimulus_area)
         return stim_current

@@ -8,7 +8,7 @@ Replaces (host side, setup only):
     src/CGx/utils/mixed_dim_problem.py:705-729.
 
 XDMF/HDF5 reading is out of scope (no h5py here): a config whose ``cell_tag_file`` is named
-``square<N>.xdmf`` / ``cube<N>.xdmf`` is generated natively; ``*.npz`` files with arrays
+``square<N>.xdmf`` / ``cube<N>.xdmf`` / ``tissue<dim>d_<N>_<m>[_g<gap>].xdmf`` is generated natively; ``*.npz`` files with arrays
 ``coords, cells, cell_tags, facets, facet_tags`` are loaded as they are.
 """
 from __future__ import annotations
@@ -97,6 +97,27 @@ def mark_subdomains_box(coords, cells, lo=0.25, hi=0.75):
     return np.where(inside, 1, 2).astype(np.int32)
 
 
+def mark_subdomains_lattice(coords, cells, N, m, gap=1):
+    """Tissue surrogate: the N^d voxel grid is cut into m^d blocks; each block holds one
+    cubic 'cell' separated from its neighbours by ``gap`` voxels of extracellular space on every side.  Cell b gets
+    tag 2 + b (one tag per cell, like ``ics_tags: !range [2, K]`` of the reference's tissue configs), ECS tag 1."""
+    if N % m:
+        raise ValueError("lattice mesh: N must be divisible by m")
+    B = N // m
+    if B - 2 * gap < 1:
+        raise ValueError("lattice mesh: blocks too small for the gap")
+    dim = coords.shape[1]
+    cen = coords[cells].mean(axis=1)
+    span = coords.max(axis=0) - coords.min(axis=0)
+    vox = np.minimum((np.floor((cen - coords.min(axis=0)) / span * N)).astype(np.int64), N - 1)
+    blk, loc = vox // B, vox % B
+    inside = ((loc >= gap) & (loc < B - gap)).all(axis=1)
+    lin = np.zeros(len(cells), dtype=np.int64)
+    for a in range(dim):
+        lin = lin * m + blk[:, a]
+    return np.where(inside, 2 + lin, 1).astype(np.int32)
+
+
 def _facet_table(cells):
     """All (cell, local facet) pairs with their sorted vertex tuples; local facet i is opposite vertex i."""
     nc, nv = cells.shape
@@ -152,7 +173,9 @@ def gamma_integration_entities(cells, cell_tags, intra_tags, extra_tags, facet_t
     cm = np.where(swap, c0[idx], c1[idx]); lm = np.where(swap, l0[idx], l1[idx])
     ent = np.column_stack([cp, lp, cm, lm]).astype(np.int32)
     tags = np.full(len(idx), 4, dtype=np.int32)
-    if facet_tags is not None:
+    if isinstance(facet_tags, str) and facet_tags == "intra":      # 'membrane tag = tag of its cell' (tissue configs)
+        tags = cell_tags[cp].astype(np.int32)
+    elif facet_tags is not None:
         fv, fvals = facet_tags
         key = {tuple(r): v for r, v in zip(np.sort(np.asarray(fv), axis=1).tolist(), np.asarray(fvals).tolist())}
         tags = np.array([key.get(tuple(r), -1) for r in fverts[idx].tolist()], dtype=np.int32)
@@ -192,6 +215,7 @@ def facet_quadrature(dim, degree=10):
 
 
 _SYN = re.compile(r"(square|cube)(\d+)")
+_TISSUE = re.compile(r"tissue(\d)d_(\d+)_(\d+)(?:_g(\d+))?")     # tissue<dim>d_<N>_<m>[_g<gap>]
 
 
 def load_mesh(mesh_file, facet_file, conversion_factor=1.0):
@@ -201,6 +225,12 @@ def load_mesh(mesh_file, facet_file, conversion_factor=1.0):
         d = np.load(mesh_file, allow_pickle=False)
         ft = (d["facets"], d["facet_tags"]) if "facets" in d.files else None
         return d["coords"] * conversion_factor, d["cells"].astype(np.int32), d["cell_tags"].astype(np.int32), ft, mesh_file
+    m = _TISSUE.search(base)
+    if m:
+        dim, N, nb, gap = int(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(4) or 1)
+        coords, cells = create_unit_square(N) if dim == 2 else create_unit_cube(N)
+        tags = mark_subdomains_lattice(coords, cells, N, nb, gap)
+        return coords * conversion_factor, cells, tags, "intra", f"generated tissue surrogate {dim}D N={N}, {nb}^{dim} cells, gap {gap}"
     m = _SYN.search(base)
     if m:
         kind, N = m.group(1), int(m.group(2))

@@ -583,10 +583,28 @@ class ProblemKNPEMI(MixedDimensionalProblem):
             roles[id(ue_p[j])] = ("KE", j)
         roles[id(self.phi_m_prev)] = ("PHIM", 0)
         self.aux_functions = []
+        # Tissue configs carry hundreds of membrane tags with the same mechanism list: tags whose compiled program is
+        # identical (same bytecode, same constant objects) share one program id.
+        # Constants somebody holds a handle to (attributes of the problem, of a mechanism, entries of the ion table) may
+        # be changed later and are compared by identity; the anonymous literals the mechanisms create inside _eval
+        # (Constant(mesh, 0.0) ...) are only reachable through the expression and are compared by value.
+        named = set()
+        for holder in [vars(self)] + [vars(m) for m in self.ionic_models] + list(self.ion_list):
+            named.update(id(v) for v in holder.values() if isinstance(v, fem.Constant))
+        ckey = lambda c: (("id", id(c)) if id(c) in named else ("v", float(c.value))) if isinstance(c, fem.Constant) else ("v", float(c))
         self.programs = {}
+        self.tag_program = {}
+        seen = {}
         for k, tag in enumerate(self.gamma_tags):
             outs = [self.ion_list[j]["I_ch"][tag] for j in range(self.N_ions)]
-            self.programs[k] = fem.compile_program(outs, roles, self.aux_functions)
+            spec = fem.compile_program(outs, roles, self.aux_functions)
+            key = (spec.code.tobytes(), tuple(ckey(c) for c in spec.const_sources))
+            if key not in seen:
+                seen[key] = len(self.programs)
+                self.programs[seen[key]] = spec
+            self.tag_program[k] = seen[key]
+        if self.backend is not None and getattr(self.backend, "tag_program", None) != self.tag_program:
+            raise RuntimeError("setup_variational_form() changed the membrane-tag -> program map after the backend was created")
         self.a = "hard-wired in knp_kernels.hip (k_assemble_pairs, k_gamma_facets, k_gamma_pairs)"
         self.L = "hard-wired in knp_kernels.hip (k_rhs, k_gamma_facets) + membrane programs"
         if self.backend is not None:

@@ -149,3 +149,20 @@ def fp32_stored(h):
         l2.A, l2.P, l2.R = rnd(lv.A), rnd(lv.P), rnd(lv.R)
         out.levels.append(l2)
     return out
+
+
+def tissue_config(dim=2, N=16, m=2, steps=2, rtol=1e-11, pc="hypre", stimulus=True):
+    """Tissue surrogate (lattice of cells, one tag per cell = its membrane tag; the shape of the reference's
+    configs/5m/100c.yaml: ics_tags range, membrane tags = cell tags, stimulus restricted to an x-range)."""
+    cfg = copy.deepcopy(CI_BASE)
+    K = m ** dim
+    cells = list(range(2, 2 + K))
+    name = f"tissue{dim}d_{N}_{m}.xdmf"
+    cfg.update({"time_steps": steps, "cell_tag_file": name, "facet_tag_file": name,
+                "ics_tags": cells, "ecs_tags": [1], "membrane_tags": cells})
+    if stimulus:
+        cfg["stimulus_tags"] = cells
+        cfg["stimulus_region"] = {"direction": "x", "range": [0.0, 0.5]}
+    cfg["solver"]["ksp_settings"]["ksp_rtol"] = rtol
+    cfg["solver"]["ksp_settings"]["pc_type"] = pc
+    return cfg
