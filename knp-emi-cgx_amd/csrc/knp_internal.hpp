@@ -51,7 +51,7 @@ int knp_build_graph(const knp_mesh_desc* m, KnpHostGraph& g);
 
 // ---- device-side program ------------------------------------------------------------------
 struct KnpProgram {
-    int n_instr = 0, n_consts = 0;
+    int n_instr = 0, n_consts = 0, n_regs = 0;
     int32_t* d_code = nullptr;
     double* d_consts = nullptr;
 };
@@ -162,6 +162,9 @@ struct knp_ctx {
     int32_t** d_prog_code = nullptr;   // device table of pointers
     double** d_prog_consts = nullptr;
     int32_t* d_prog_len = nullptr;
+    int32_t* d_prog_nconsts = nullptr;
+    int prog_regs = 0, prog_len_cap = 0, prog_consts_cap = 0;   // maxima over the programs (LDS sizing of k_gamma_facets)
+    size_t gamma_lds_set = 0;
     bool progs_dirty = true;
     int max_prog = -1;
     // sources

@@ -97,14 +97,15 @@ __global__ void __launch_bounds__(NT) k_cell_means(int n_c, int nv1, const int32
         const double* k = s ? f.ke[j] : f.ki[j];
         double acc = 0.0;
         for (int a = 0; a < nv1; ++a) acc += k[cells[(size_t)c * nv1 + a]];
-        cbar[(size_t)j * n_c + c] = acc * inv;
+        cbar[(size_t)4 * c + j] = acc * inv;     // 32-B record per cell: one gather per contribution in K1
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // K1: volume blocks, one thread per node pair
 // ------------------------------------------------------------------------------------------
-template <bool PRECOND, bool TD_ONLY>   // TD_ONLY: write only the entries that depend on the previous solution
+#define ASM_G 1   // lanes per node pair in K1 (4 lanes: -4 % on cube64, +6 % on square512 -- not worth a second instantiation)
+template <bool PRECOND, bool TD_ONLY, int G>   // TD_ONLY: write only the entries that depend on the previous solution; G lanes per pair
 __global__ void __launch_bounds__(NT)
 k_assemble_pairs(int64_t n_pairs, int n_c, DevParams P, const int32_t* __restrict__ pair_row,
                  const int32_t* __restrict__ pair_ptr, const uint8_t* __restrict__ node_side,
@@ -112,22 +113,34 @@ k_assemble_pairs(int64_t n_pairs, int n_c, DevParams P, const int32_t* __restric
                  const int32_t* __restrict__ contrib_ptr, const int32_t* __restrict__ contrib_cell,
                  const double* __restrict__ contrib_k, const double* __restrict__ cbar,
                  const int32_t* __restrict__ rowptr, double* __restrict__ vals) {
-    int64_t p = (int64_t)blockIdx.x * NT + threadIdx.x;
-    if (p >= n_pairs) return;
+    // (gathering once per unordered pair and mirroring the entries was tried: the indirection and the scattered mirror
+    // writes cost more than the halved gathers save -- 15 % slower on cube64)
+    const int64_t p_raw = ((int64_t)blockIdx.x * NT + threadIdx.x) / G;
+    const int lane = threadIdx.x & (G - 1);
+    const bool live = p_raw < n_pairs;
+    const int64_t p = live ? p_raw : n_pairs - 1;     // surplus lanes shadow the last pair (uniform shuffles), they do not write
     const int n = pair_row[p];
     const int p0 = pair_ptr[n];
     const int q = (int)(p - p0);
-    const int deg = pair_ptr[n + 1] - p0;
     const int side = node_side[n];
     double S0 = 0, S1 = 0, S2 = 0;
     const int c1 = contrib_ptr[p + 1];
-    for (int c = contrib_ptr[p]; c < c1; ++c) {
+    for (int c = contrib_ptr[p] + lane; c < c1; c += G) {
         const int cell = contrib_cell[c];
         const double k = contrib_k[c];
-        S0 += k * cbar[cell];
-        S1 += k * cbar[(size_t)n_c + cell];
-        S2 += k * cbar[(size_t)2 * n_c + cell];
+        const double2 c01 = *reinterpret_cast<const double2*>(cbar + (size_t)4 * cell);
+        const double c2 = cbar[(size_t)4 * cell + 2];
+        S0 += k * c01.x;
+        S1 += k * c01.y;
+        S2 += k * c2;
     }
+#pragma unroll
+    for (int o = G >> 1; o > 0; o >>= 1) {
+        S0 += __shfl_xor(S0, o, G);
+        S1 += __shfl_xor(S1, o, G);
+        S2 += __shfl_xor(S2, o, G);
+    }
+    if (!live || lane != 0) return;
     const double S[3] = {S0, S1, S2};
     const double M = pair_M[p], K = pair_K[p];
     double phiphi = 0.0;
@@ -148,7 +161,6 @@ k_assemble_pairs(int64_t n_pairs, int n_c, DevParams P, const int32_t* __restric
         vals[rphi + 4 * q + 3] = phiphi;
     } else {
         // P is stored pair-major: the 4 per-field entries of a node pair are contiguous (32 B)
-        (void)deg;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const double D = side ? P.De[j] : P.Di[j];
@@ -175,64 +187,105 @@ __device__ __forceinline__ double powi_d(double x, int e) {
     return neg ? 1.0 / r : r;
 }
 
-__device__ void run_program(const int32_t* __restrict__ code, int n_instr, const double* __restrict__ consts,
-                            const double* ki, const double* ke, double phim, const double* aux, const double* xq,
-                            double* Iout) {
-    double reg[KNP_MAX_PROG_REGS];
+// The register file lives in LDS (a private array indexed by the instruction stream would be spilled to scratch
+// memory): register r of evaluation s of thread t sits at reg[(r*QV + s)*BT + t] -- one column per thread, conflict-free.
+// Each interpreted instruction is executed for QV quadrature points at once: the decode, the branch and the LDS
+// latency are paid once per instruction and the QV independent evaluations overlap.  `code` / `consts` point to LDS
+// when the whole block runs the same program (the usual case), to global memory otherwise.
+// The caller guarantees that every active lane of the wave runs the same program, so the instruction words are
+// wave-uniform: readfirstlane moves them to scalar registers (scalar branch, scalar address arithmetic), and the next
+// instruction is fetched while the current one executes.
+template <int QV, int BT>
+__device__ __forceinline__ void run_program(const int32_t* code, int n_instr, const double* consts,
+                                            const double (*ki)[3], const double (*ke)[3], const double* phim,
+                                            const double (*aux)[KNP_MAX_AUX], const double (*xq)[3], double (*Iout)[3], double* reg) {
+#define RG(i, s) reg[((i) * QV + (s)) * BT]
+#define EACH for (int s_ = 0; s_ < QV; ++s_)
+#define UN(expr)                                                       \
+    _Pragma("unroll") EACH { const double x = RG(a, s_); RG(d, s_) = (expr); } \
+    break
+#define BIN(expr)                                                                             \
+    _Pragma("unroll") EACH { const double x = RG(a, s_), y = RG(b, s_); RG(d, s_) = (expr); } \
+    break
+    int4 nxt = n_instr > 0 ? *reinterpret_cast<const int4*>(code) : make_int4(0, 0, 0, 0);
     for (int i = 0; i < n_instr; ++i) {
-        const int op = code[4 * i], d = code[4 * i + 1], a = code[4 * i + 2], b = code[4 * i + 3];
+        const int4 ins = nxt;
+        if (i + 1 < n_instr) nxt = *reinterpret_cast<const int4*>(code + 4 * (i + 1));
+        const int op = __builtin_amdgcn_readfirstlane(ins.x), d = __builtin_amdgcn_readfirstlane(ins.y),
+                  a = __builtin_amdgcn_readfirstlane(ins.z), b = __builtin_amdgcn_readfirstlane(ins.w);
         switch (op) {
-            case KNP_OP_CONST: reg[d] = consts[a]; break;
-            case KNP_OP_KI: reg[d] = ki[a]; break;
-            case KNP_OP_KE: reg[d] = ke[a]; break;
-            case KNP_OP_PHIM: reg[d] = phim; break;
-            case KNP_OP_AUX: reg[d] = aux[a]; break;
-            case KNP_OP_X: reg[d] = xq[a]; break;
-            case KNP_OP_ADD: reg[d] = reg[a] + reg[b]; break;
-            case KNP_OP_SUB: reg[d] = reg[a] - reg[b]; break;
-            case KNP_OP_MUL: reg[d] = reg[a] * reg[b]; break;
-            case KNP_OP_DIV: reg[d] = reg[a] / reg[b]; break;
-            case KNP_OP_NEG: reg[d] = -reg[a]; break;
-            case KNP_OP_POW: reg[d] = pow(reg[a], reg[b]); break;
-            case KNP_OP_LN: reg[d] = log(reg[a]); break;
-            case KNP_OP_EXP: reg[d] = exp(reg[a]); break;
-            case KNP_OP_SQRT: reg[d] = sqrt(reg[a]); break;
-            case KNP_OP_MAX: reg[d] = fmax(reg[a], reg[b]); break;
-            case KNP_OP_MIN: reg[d] = fmin(reg[a], reg[b]); break;
-            case KNP_OP_ABS: reg[d] = fabs(reg[a]); break;
-            case KNP_OP_LT: reg[d] = reg[a] < reg[b] ? 1.0 : 0.0; break;
-            case KNP_OP_GT: reg[d] = reg[a] > reg[b] ? 1.0 : 0.0; break;
-            case KNP_OP_LE: reg[d] = reg[a] <= reg[b] ? 1.0 : 0.0; break;
-            case KNP_OP_GE: reg[d] = reg[a] >= reg[b] ? 1.0 : 0.0; break;
-            case KNP_OP_EQ: reg[d] = reg[a] == reg[b] ? 1.0 : 0.0; break;
-            case KNP_OP_AND: reg[d] = (reg[a] != 0.0 && reg[b] != 0.0) ? 1.0 : 0.0; break;
-            case KNP_OP_OR: reg[d] = (reg[a] != 0.0 || reg[b] != 0.0) ? 1.0 : 0.0; break;
-            case KNP_OP_NOT: reg[d] = reg[a] != 0.0 ? 0.0 : 1.0; break;
-            case KNP_OP_SEL: reg[d] = reg[a] != 0.0 ? reg[b] : reg[d]; break;
-            case KNP_OP_OUT: Iout[a] += reg[b]; break;
-            case KNP_OP_MOV: reg[d] = reg[a]; break;
-            case KNP_OP_POWI: reg[d] = powi_d(reg[a], b); break;
+            case KNP_OP_CONST: { const double c = consts[a];
+#pragma unroll
+                EACH RG(d, s_) = c; } break;
+            case KNP_OP_KI:
+#pragma unroll
+                EACH RG(d, s_) = ki[s_][a]; break;
+            case KNP_OP_KE:
+#pragma unroll
+                EACH RG(d, s_) = ke[s_][a]; break;
+            case KNP_OP_PHIM:
+#pragma unroll
+                EACH RG(d, s_) = phim[s_]; break;
+            case KNP_OP_AUX:
+#pragma unroll
+                EACH RG(d, s_) = aux[s_][a]; break;
+            case KNP_OP_X:
+#pragma unroll
+                EACH RG(d, s_) = xq[s_][a]; break;
+            case KNP_OP_ADD: BIN(x + y);
+            case KNP_OP_SUB: BIN(x - y);
+            case KNP_OP_MUL: BIN(x * y);
+            case KNP_OP_DIV: BIN(x / y);
+            case KNP_OP_NEG: UN(-x);
+            case KNP_OP_POW: BIN(pow(x, y));
+            case KNP_OP_LN: UN(log(x));
+            case KNP_OP_EXP: UN(exp(x));
+            case KNP_OP_SQRT: UN(sqrt(x));
+            case KNP_OP_MAX: BIN(fmax(x, y));
+            case KNP_OP_MIN: BIN(fmin(x, y));
+            case KNP_OP_ABS: UN(fabs(x));
+            case KNP_OP_LT: BIN(x < y ? 1.0 : 0.0);
+            case KNP_OP_GT: BIN(x > y ? 1.0 : 0.0);
+            case KNP_OP_LE: BIN(x <= y ? 1.0 : 0.0);
+            case KNP_OP_GE: BIN(x >= y ? 1.0 : 0.0);
+            case KNP_OP_EQ: BIN(x == y ? 1.0 : 0.0);
+            case KNP_OP_AND: BIN((x != 0.0 && y != 0.0) ? 1.0 : 0.0);
+            case KNP_OP_OR: BIN((x != 0.0 || y != 0.0) ? 1.0 : 0.0);
+            case KNP_OP_NOT: UN(x != 0.0 ? 0.0 : 1.0);
+            case KNP_OP_SEL:
+#pragma unroll
+                EACH { if (RG(a, s_) != 0.0) RG(d, s_) = RG(b, s_); } break;
+            case KNP_OP_OUT:
+#pragma unroll
+                EACH Iout[s_][a] += RG(b, s_); break;
+            case KNP_OP_MOV: UN(x);
+            case KNP_OP_POWI: UN(powi_d(x, b));
             default: break;
         }
     }
+#undef BIN
+#undef UN
+#undef EACH
+#undef RG
 }
 
 // ------------------------------------------------------------------------------------------
-// K2: membrane facet quadrature.  LF lanes per facet, each lane takes the quadrature points q = lane,
-//     lane+LF, ...; partial sums are combined with a fixed shuffle tree (deterministic).
+// K2: membrane facet quadrature.  LF lanes per facet; a lane takes the quadrature points q = lane + LF*s, QV of them
+//     at a time; partial sums are combined with a fixed shuffle tree (deterministic).
 //   fmat[(k*NPK + ab)*n_g + g], k = 0..2 intra ions, 3..5 extra ions : M_Gamma[alpha^k C_M/(F z_k)]
 //   fvec[(k*DIM + a)*n_g + g],  k = 0..2 intra, 3..5 extra, 6 potential
 // ------------------------------------------------------------------------------------------
-template <int DIM, bool MAT, bool VEC, int LF>
-__global__ void __launch_bounds__(NT)
+template <int DIM, bool MAT, bool VEC, int LF, int QV, int BT, int OCC>
+__global__ void __launch_bounds__(BT, OCC)
 k_gamma_facets(int n_g, int n_q, DevParams P, const int32_t* __restrict__ fv, const double* __restrict__ fmeas,
                const double* __restrict__ qp, const double* __restrict__ qw, FieldPtrs f, int n_aux,
                const double* __restrict__ coords, const int32_t* __restrict__ gamma_prog,
                const int32_t* const* __restrict__ prog_code, const int32_t* __restrict__ prog_len,
-               const double* const* __restrict__ prog_consts, double* __restrict__ fmat,
-               double* __restrict__ fvec) {
+               const double* const* __restrict__ prog_consts, const int32_t* __restrict__ prog_nconsts, int n_regs,
+               int consts_cap, double* __restrict__ fmat, double* __restrict__ fvec) {
     constexpr int NPK = DIM * (DIM + 1) / 2;
-    const int g_raw = (blockIdx.x * NT + threadIdx.x) / LF;
+    extern __shared__ double smem[];   // VEC only: [n_regs][QV][BT] register file | [consts_cap] constants | program code
+    const int g_raw = (blockIdx.x * BT + threadIdx.x) / LF;
     const int qlane = threadIdx.x & (LF - 1);
     const bool live = g_raw < n_g;
     const int g = live ? g_raw : n_g - 1;      // idle lanes shadow the last facet so that shuffles stay uniform
@@ -265,84 +318,133 @@ k_gamma_facets(int n_g, int n_q, DevParams P, const int32_t* __restrict__ fv, co
             for (int a = 0; a < DIM; ++a) av[k][a] = 0.0;
     }
     const int prog = VEC ? gamma_prog[g] : 0;
-    for (int q = qlane; q < n_q; q += LF) {
-        double lam[DIM];
+    const int32_t* code = nullptr;
+    const double* consts = nullptr;
+    int n_instr = 0;
+    if (VEC) {
+        __shared__ int s_p0;
+        if (threadIdx.x == 0) s_p0 = prog;
+        __syncthreads();
+        const int p0 = s_p0;
+        n_instr = prog_len[prog];
+        if (__syncthreads_and(prog == p0)) {      // one program for the whole block: run it out of LDS
+            double* sconst = smem + (size_t)n_regs * QV * BT;
+            int32_t* scode = reinterpret_cast<int32_t*>(sconst + consts_cap);
+            const int32_t* gc = prog_code[p0];
+            const double* gk = prog_consts[p0];
+            for (int i = threadIdx.x; i < 4 * n_instr; i += BT) scode[i] = gc[i];
+            for (int i = threadIdx.x; i < prog_nconsts[p0]; i += BT) sconst[i] = gk[i];
+            __syncthreads();
+            code = scode;
+            consts = sconst;
+        }   // else: code stays null and every wave walks through its distinct programs one at a time (below)
+    }
+    for (int q0 = qlane; q0 < n_q; q0 += LF * QV) {
+        double lam[QV][DIM], w[QV], kiq[QV][3], keq[QV][3], phq[QV], ali[QV][3], ale[QV][3];
 #pragma unroll
-        for (int a = 0; a < DIM; ++a) lam[a] = qp[q * DIM + a];
-        const double w = qw[q] * meas;
-        double kiq[3], keq[3], phq = 0.0;
+        for (int s = 0; s < QV; ++s) {
+            const int qq = q0 + s * LF;
+            const bool on = qq < n_q;
+            const int q = on ? qq : q0;               // surplus slots repeat a valid point with weight zero
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            double si = 0.0, se = 0.0;
-#pragma unroll
-            for (int a = 0; a < DIM; ++a) {
-                si += lam[a] * ki[j][a];
-                se += lam[a] * ke[j][a];
-            }
-            kiq[j] = si;
-            keq[j] = se;
-        }
-#pragma unroll
-        for (int a = 0; a < DIM; ++a) phq += lam[a] * pm[a];
-        double deni = 0.0, dene = 0.0;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            deni += P.Di[j] * P.z[j] * P.z[j] * kiq[j];
-            dene += P.De[j] * P.z[j] * P.z[j] * keq[j];
-        }
-        double ali[3], ale[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            ali[j] = P.Di[j] * P.z[j] * P.z[j] * kiq[j] / deni;
-            ale[j] = P.De[j] * P.z[j] * P.z[j] * keq[j] / dene;
-        }
-        if (MAT) {
+            for (int a = 0; a < DIM; ++a) lam[s][a] = qp[q * DIM + a];
+            w[s] = on ? qw[q] * meas : 0.0;
+            phq[s] = 0.0;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const double wi = w * ali[j] * P.C_M / (P.F * P.z[j]);
-                const double we = w * ale[j] * P.C_M / (P.F * P.z[j]);
-                int idx = 0;
+                double si = 0.0, se = 0.0;
 #pragma unroll
-                for (int a = 0; a < DIM; ++a)
+                for (int a = 0; a < DIM; ++a) {
+                    si += lam[s][a] * ki[j][a];
+                    se += lam[s][a] * ke[j][a];
+                }
+                kiq[s][j] = si;
+                keq[s][j] = se;
+            }
 #pragma unroll
-                    for (int b = a; b < DIM; ++b) {
-                        const double ll = lam[a] * lam[b];
-                        am[j][idx] += wi * ll;
-                        am[3 + j][idx] += we * ll;
-                        ++idx;
-                    }
+            for (int a = 0; a < DIM; ++a) phq[s] += lam[s][a] * pm[a];
+            double deni = 0.0, dene = 0.0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                deni += P.Di[j] * P.z[j] * P.z[j] * kiq[s][j];
+                dene += P.De[j] * P.z[j] * P.z[j] * keq[s][j];
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                ali[s][j] = P.Di[j] * P.z[j] * P.z[j] * kiq[s][j] / deni;
+                ale[s][j] = P.De[j] * P.z[j] * P.z[j] * keq[s][j] / dene;
+            }
+            if (MAT) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const double wi = w[s] * ali[s][j] * P.C_M / (P.F * P.z[j]);
+                    const double we = w[s] * ale[s][j] * P.C_M / (P.F * P.z[j]);
+                    int idx = 0;
+#pragma unroll
+                    for (int a = 0; a < DIM; ++a)
+#pragma unroll
+                        for (int b = a; b < DIM; ++b) {
+                            const double ll = lam[s][a] * lam[s][b];
+                            am[j][idx] += wi * ll;
+                            am[3 + j][idx] += we * ll;
+                            ++idx;
+                        }
+                }
             }
         }
         if (VEC) {
-            double auxq[KNP_MAX_AUX], xq[3] = {0, 0, 0}, Iout[3] = {0, 0, 0};
-            for (int k = 0; k < n_aux; ++k) {
-                double s = 0.0;
+            double auxq[QV][KNP_MAX_AUX], xq[QV][3], Iout[QV][3];
 #pragma unroll
-                for (int a = 0; a < DIM; ++a) s += lam[a] * f.aux[k][v[a]];
-                auxq[k] = s;
-            }
+            for (int s = 0; s < QV; ++s) {
+                for (int k = 0; k < n_aux; ++k) {
+                    double t = 0.0;
 #pragma unroll
-            for (int d = 0; d < DIM; ++d) {
-                double s = 0.0;
+                    for (int a = 0; a < DIM; ++a) t += lam[s][a] * f.aux[k][v[a]];
+                    auxq[s][k] = t;
+                }
 #pragma unroll
-                for (int a = 0; a < DIM; ++a) s += lam[a] * coords[(size_t)v[a] * DIM + d];
-                xq[d] = s;
-            }
-            run_program(prog_code[prog], prog_len[prog], prog_consts[prog], kiq, keq, phq, auxq, xq, Iout);
-            const double Itot = Iout[0] + Iout[1] + Iout[2];
+                for (int d = 0; d < 3; ++d) {
+                    double t = 0.0;
+                    if (d < DIM) {
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const double gi = w * (P.dt * Iout[j] - ali[j] * P.C_M * phq) / (P.F * P.z[j]);
-                const double ge = w * (P.dt * Iout[j] - ale[j] * P.C_M * phq) / (P.F * P.z[j]);
-#pragma unroll
-                for (int a = 0; a < DIM; ++a) {
-                    av[j][a] += gi * lam[a];
-                    av[3 + j][a] += ge * lam[a];
+                        for (int a = 0; a < DIM; ++a) t += lam[s][a] * coords[(size_t)v[a] * DIM + d];
+                    }
+                    xq[s][d] = t;
+                    Iout[s][d] = 0.0;
                 }
             }
-            const double gp = w * (P.dt * Itot - P.C_M * phq) / P.F;
+            double* reg = smem + threadIdx.x;
+            if (code) {
+                run_program<QV, BT>(code, n_instr, consts, kiq, keq, phq, auxq, xq, Iout, reg);
+            } else {   // mixed block: serialise over the programs present in this wave (the interpreter needs uniform code)
+                bool pending = true;
+                while (true) {
+                    const unsigned long long m = __ballot(pending);
+                    if (!m) break;
+                    const int pl = __shfl(prog, __ffsll((long long)m) - 1);
+                    if (pending && prog == pl) {
+                        run_program<QV, BT>(prog_code[pl], prog_len[pl], prog_consts[pl], kiq, keq, phq, auxq, xq, Iout, reg);
+                        pending = false;
+                    }
+                }
+            }
 #pragma unroll
-            for (int a = 0; a < DIM; ++a) av[6][a] += gp * lam[a];
+            for (int s = 0; s < QV; ++s) {
+                const double Itot = Iout[s][0] + Iout[s][1] + Iout[s][2];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const double gi = w[s] * (P.dt * Iout[s][j] - ali[s][j] * P.C_M * phq[s]) / (P.F * P.z[j]);
+                    const double ge = w[s] * (P.dt * Iout[s][j] - ale[s][j] * P.C_M * phq[s]) / (P.F * P.z[j]);
+#pragma unroll
+                    for (int a = 0; a < DIM; ++a) {
+                        av[j][a] += gi * lam[s][a];
+                        av[3 + j][a] += ge * lam[s][a];
+                    }
+                }
+                const double gp = w[s] * (P.dt * Itot - P.C_M * phq[s]) / P.F;
+#pragma unroll
+                for (int a = 0; a < DIM; ++a) av[6][a] += gp * lam[s][a];
+            }
         }
     }
     if (MAT) {
@@ -1352,6 +1454,7 @@ int knp_create(knp_ctx** out, const knp_mesh_desc* mesh) {
     KCHK(dev_upload(ctx, &ctx->d_pair_M, g.pair_M));
     KCHK(dev_upload(ctx, &ctx->d_pair_K, g.pair_K));
     KCHK(dev_upload(ctx, &ctx->d_contrib_ptr, g.contrib_ptr));
+
     KCHK(dev_upload(ctx, &ctx->d_contrib_cell, g.contrib_cell));
     KCHK(dev_upload(ctx, &ctx->d_contrib_k, g.contrib_k));
     KCHK(dev_upload(ctx, &ctx->d_fv, g.fv));
@@ -1388,7 +1491,8 @@ int knp_create(knp_ctx** out, const knp_mesh_desc* mesh) {
     HIPCHK(hipMalloc((void**)&ctx->d_p_vals, std::max<int64_t>(4 * ctx->n_pairs, 1) * sizeof(double)));
     HIPCHK(hipMemset(ctx->d_p_vals, 0, std::max<int64_t>(4 * ctx->n_pairs, 1) * sizeof(double)));
     const int npk = dim * (dim + 1) / 2;
-    HIPCHK(hipMalloc((void**)&ctx->d_cbar, (size_t)3 * g.n_c * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&ctx->d_cbar, (size_t)4 * std::max(g.n_c, 1) * sizeof(double)));
+    HIPCHK(hipMemset(ctx->d_cbar, 0, (size_t)4 * std::max(g.n_c, 1) * sizeof(double)));
     HIPCHK(hipMalloc((void**)&ctx->d_fmat, std::max<size_t>((size_t)6 * npk * g.n_g, 1) * sizeof(double)));
     HIPCHK(hipMalloc((void**)&ctx->d_fvec, std::max<size_t>((size_t)7 * dim * g.n_g, 1) * sizeof(double)));
     HIPCHK(hipMalloc((void**)&ctx->d_partial, (size_t)RED_SLOTS * RED_BLOCKS * sizeof(double)));
@@ -1441,7 +1545,7 @@ int knp_destroy(knp_ctx* ctx) {
     if (ctx->h_seq) (void)hipHostFree((void*)ctx->h_seq);
     dev_free(ctx->d_V); dev_free(ctx->d_w); dev_free(ctx->d_t);
     for (auto& p : ctx->progs) { dev_free(p.d_code); dev_free(p.d_consts); }
-    dev_free(ctx->d_prog_code); dev_free(ctx->d_prog_consts); dev_free(ctx->d_prog_len);
+    dev_free(ctx->d_prog_code); dev_free(ctx->d_prog_consts); dev_free(ctx->d_prog_len); dev_free(ctx->d_prog_nconsts);
     for (int h = 0; h < KNP_MAX_HIER; ++h) {
         KnpAmgHier& H = ctx->hier[h];
         for (int l = 0; l < KNP_MAX_AMG_LEVELS; ++l) {
@@ -1549,10 +1653,11 @@ int knp_set_params(knp_ctx* ctx, double dt, double F, double C_M, double psi, in
     return KNP_OK;
 }
 
-static int validate_program(knp_ctx* ctx, int n_instr, const int32_t* code, int n_consts) {
+static int validate_program(knp_ctx* ctx, int n_instr, const int32_t* code, int n_consts, int* n_regs_out) {
+    int max_reg = -1;
     for (int i = 0; i < n_instr; ++i) {
         const int op = code[4 * i], d = code[4 * i + 1], a = code[4 * i + 2], b = code[4 * i + 3];
-        auto regok = [](int r) { return r >= 0 && r < KNP_MAX_PROG_REGS; };
+        auto regok = [&](int r) { if (r > max_reg) max_reg = r; return r >= 0 && r < KNP_MAX_PROG_REGS; };
         bool ok = true;
         switch (op) {
             case KNP_OP_CONST: ok = regok(d) && a >= 0 && a < n_consts; break;
@@ -1567,15 +1672,18 @@ static int validate_program(knp_ctx* ctx, int n_instr, const int32_t* code, int 
         }
         if (!ok) { ctx->err = "invalid membrane program instruction " + std::to_string(i); return KNP_E_ARG; }
     }
+    *n_regs_out = max_reg + 1;
     return KNP_OK;
 }
 
 int knp_set_program(knp_ctx* ctx, int32_t id, int32_t n_instr, const int32_t* code, int32_t n_consts, const double* consts) {
     CHECK_CTX(ctx);
     if (id < 0 || id > 4096 || n_instr < 0 || (n_instr && !code) || n_consts < 0 || (n_consts && !consts)) { ctx->err = "bad program arguments"; return KNP_E_ARG; }
-    KCHK(validate_program(ctx, n_instr, code, n_consts));
+    int n_regs = 0;
+    KCHK(validate_program(ctx, n_instr, code, n_consts, &n_regs));
     if ((int)ctx->progs.size() <= id) ctx->progs.resize(id + 1);
     KnpProgram& p = ctx->progs[id];
+    p.n_regs = n_regs;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     dev_free(p.d_code); dev_free(p.d_consts);
     p.n_instr = n_instr; p.n_consts = n_consts;
@@ -1596,13 +1704,21 @@ static int sync_program_table(knp_ctx* ctx) {
     const size_t np = std::max<size_t>(ctx->progs.size(), 1);
     std::vector<int32_t*> codes(np, nullptr);
     std::vector<double*> consts(np, nullptr);
-    std::vector<int32_t> lens(np, 0);
-    for (size_t i = 0; i < ctx->progs.size(); ++i) { codes[i] = ctx->progs[i].d_code; consts[i] = ctx->progs[i].d_consts; lens[i] = ctx->progs[i].n_instr; }
+    std::vector<int32_t> lens(np, 0), ncs(np, 0);
+    ctx->prog_regs = ctx->prog_len_cap = ctx->prog_consts_cap = 0;
+    for (size_t i = 0; i < ctx->progs.size(); ++i) {
+        const KnpProgram& pr = ctx->progs[i];
+        codes[i] = pr.d_code; consts[i] = pr.d_consts; lens[i] = pr.n_instr; ncs[i] = pr.n_consts;
+        ctx->prog_regs = std::max(ctx->prog_regs, pr.n_regs);
+        ctx->prog_len_cap = std::max(ctx->prog_len_cap, pr.n_instr);
+        ctx->prog_consts_cap = std::max(ctx->prog_consts_cap, pr.n_consts);
+    }
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    dev_free(ctx->d_prog_code); dev_free(ctx->d_prog_consts); dev_free(ctx->d_prog_len);
+    dev_free(ctx->d_prog_code); dev_free(ctx->d_prog_consts); dev_free(ctx->d_prog_len); dev_free(ctx->d_prog_nconsts);
     KCHK(dev_upload(ctx, &ctx->d_prog_code, codes));
     KCHK(dev_upload(ctx, &ctx->d_prog_consts, consts));
     KCHK(dev_upload(ctx, &ctx->d_prog_len, lens));
+    KCHK(dev_upload(ctx, &ctx->d_prog_nconsts, ncs));
     ctx->progs_dirty = false;
     return KNP_OK;
 }
@@ -1658,26 +1774,26 @@ int knp_assemble_matrix(knp_ctx* ctx, const knp_fields* fields) {
     const bool td_only = ctx->have_A && !ctx->asm_full && ctx->asm_dt == ctx->dt;
     if (ctx->n_pairs) {
         if (td_only)
-            hipLaunchKernelGGL((k_assemble_pairs<false, true>), dim3(nblocks(ctx->n_pairs)), dim3(NT), 0, ctx->stream, ctx->n_pairs,
+            hipLaunchKernelGGL((k_assemble_pairs<false, true, ASM_G>), dim3(nblocks(ctx->n_pairs * ASM_G)), dim3(NT), 0, ctx->stream, ctx->n_pairs,
                                g.n_c, P, ctx->d_pair_row, ctx->d_pair_ptr, ctx->d_node_side, ctx->d_pair_M, ctx->d_pair_K,
                                ctx->d_contrib_ptr, ctx->d_contrib_cell, ctx->d_contrib_k, ctx->d_cbar, ctx->d_rowptr, ctx->d_vals);
         else
-            hipLaunchKernelGGL((k_assemble_pairs<false, false>), dim3(nblocks(ctx->n_pairs)), dim3(NT), 0, ctx->stream, ctx->n_pairs,
+            hipLaunchKernelGGL((k_assemble_pairs<false, false, ASM_G>), dim3(nblocks(ctx->n_pairs * ASM_G)), dim3(NT), 0, ctx->stream, ctx->n_pairs,
                                g.n_c, P, ctx->d_pair_row, ctx->d_pair_ptr, ctx->d_node_side, ctx->d_pair_M, ctx->d_pair_K,
                                ctx->d_contrib_ptr, ctx->d_contrib_cell, ctx->d_contrib_k, ctx->d_cbar, ctx->d_rowptr, ctx->d_vals);
     }
     ctx->asm_dt = ctx->dt;
     if (g.n_g > 0) {
         if (g.dim == 2)
-            hipLaunchKernelGGL((k_gamma_facets<2, true, false, 8>), dim3(nblocks((int64_t)g.n_g * 8)), dim3(NT), 0, ctx->stream, g.n_g, g.n_q, P,
+            hipLaunchKernelGGL((k_gamma_facets<2, true, false, 8, 1, NT, 1>), dim3(nblocks((int64_t)g.n_g * 8)), dim3(NT), 0, ctx->stream, g.n_g, g.n_q, P,
                                ctx->d_fv, ctx->d_fmeas, ctx->d_qp, ctx->d_qw, f, 0, ctx->d_coords, ctx->d_gamma_prog,
                                (const int32_t* const*)nullptr, (const int32_t*)nullptr, (const double* const*)nullptr,
-                               ctx->d_fmat, ctx->d_fvec);
+                               (const int32_t*)nullptr, 0, 0, ctx->d_fmat, ctx->d_fvec);
         else
-            hipLaunchKernelGGL((k_gamma_facets<3, true, false, 32>), dim3(nblocks((int64_t)g.n_g * 32)), dim3(NT), 0, ctx->stream, g.n_g, g.n_q, P,
+            hipLaunchKernelGGL((k_gamma_facets<3, true, false, 32, 1, NT, 1>), dim3(nblocks((int64_t)g.n_g * 32)), dim3(NT), 0, ctx->stream, g.n_g, g.n_q, P,
                                ctx->d_fv, ctx->d_fmeas, ctx->d_qp, ctx->d_qw, f, 0, ctx->d_coords, ctx->d_gamma_prog,
                                (const int32_t* const*)nullptr, (const int32_t*)nullptr, (const double* const*)nullptr,
-                               ctx->d_fmat, ctx->d_fvec);
+                               (const int32_t*)nullptr, 0, 0, ctx->d_fmat, ctx->d_fvec);
         if (ctx->n_gp)
             hipLaunchKernelGGL((k_gamma_pairs<false>), dim3(nblocks(ctx->n_gp)), dim3(NT), 0, ctx->stream, ctx->n_gp, g.n_g, g.dim, P,
                                ctx->d_grow, ctx->d_gptr, ctx->d_gv_node_i, ctx->d_gv_node_e, ctx->d_gq_i, ctx->d_gq_e,
@@ -1711,7 +1827,7 @@ int knp_assemble_precond(knp_ctx* ctx, const knp_fields* fields) {
     hipLaunchKernelGGL(k_cell_means, dim3(nblocks(g.n_c)), dim3(NT), 0, ctx->stream, g.n_c, g.nv1, ctx->d_cells,
                        ctx->d_cell_side, f, ctx->d_cbar);
     if (ctx->n_pairs)
-        hipLaunchKernelGGL((k_assemble_pairs<true, false>), dim3(nblocks(ctx->n_pairs)), dim3(NT), 0, ctx->stream, ctx->n_pairs,
+        hipLaunchKernelGGL((k_assemble_pairs<true, false, ASM_G>), dim3(nblocks(ctx->n_pairs * ASM_G)), dim3(NT), 0, ctx->stream, ctx->n_pairs,
                            g.n_c, P, ctx->d_pair_row, ctx->d_pair_ptr, ctx->d_node_side, ctx->d_pair_M, ctx->d_pair_K,
                            ctx->d_contrib_ptr, ctx->d_contrib_cell, ctx->d_contrib_k, ctx->d_cbar, ctx->d_rowptr, ctx->d_p_vals);
     if (g.n_g > 0 && ctx->n_gp)
@@ -1748,16 +1864,26 @@ int knp_assemble_rhs(knp_ctx* ctx, const knp_fields* fields, double* b) {
     }
     ProfScope ps(ctx, 3);
     if (g.n_g > 0) {
-        if (g.dim == 2)
-            hipLaunchKernelGGL((k_gamma_facets<2, false, true, 8>), dim3(nblocks((int64_t)g.n_g * 8)), dim3(NT), 0, ctx->stream, g.n_g, g.n_q, P,
-                               ctx->d_fv, ctx->d_fmeas, ctx->d_qp, ctx->d_qw, f, n_aux, ctx->d_coords, ctx->d_gamma_prog,
-                               (const int32_t* const*)ctx->d_prog_code, (const int32_t*)ctx->d_prog_len,
-                               (const double* const*)ctx->d_prog_consts, ctx->d_fmat, ctx->d_fvec);
-        else
-            hipLaunchKernelGGL((k_gamma_facets<3, false, true, 32>), dim3(nblocks((int64_t)g.n_g * 32)), dim3(NT), 0, ctx->stream, g.n_g, g.n_q, P,
-                               ctx->d_fv, ctx->d_fmeas, ctx->d_qp, ctx->d_qw, f, n_aux, ctx->d_coords, ctx->d_gamma_prog,
-                               (const int32_t* const*)ctx->d_prog_code, (const int32_t*)ctx->d_prog_len,
-                               (const double* const*)ctx->d_prog_consts, ctx->d_fmat, ctx->d_fvec);
+        // dynamic LDS: register file [n_regs][NT] | constants | code of the block's program
+        const int n_regs = std::max(ctx->prog_regs, 1), ccap = (std::max(ctx->prog_consts_cap, 1) + 1) & ~1;   // even: code stays 16-B aligned
+#define GF_LAUNCH(D, L, Q, B, O)                                                                                              \
+    do {                                                                                                                      \
+        const size_t lds = ((size_t)n_regs * Q * B + ccap) * sizeof(double) + (size_t)4 * std::max(ctx->prog_len_cap, 1) * sizeof(int32_t); \
+        if (lds > 160 * 1024) { ctx->err = "membrane programs need more LDS than a CU has"; return KNP_E_STATE; }             \
+        if (lds != ctx->gamma_lds_set)                                                                                        \
+            HIPCHK(hipFuncSetAttribute((const void*)k_gamma_facets<D, false, true, L, Q, B, O>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        ctx->gamma_lds_set = lds;                                                                                             \
+        hipLaunchKernelGGL((k_gamma_facets<D, false, true, L, Q, B, O>), dim3((unsigned)(((int64_t)g.n_g * L + B - 1) / B)), dim3(B), lds, \
+                           ctx->stream, g.n_g, g.n_q, P, ctx->d_fv, ctx->d_fmeas, ctx->d_qp, ctx->d_qw, f, n_aux, ctx->d_coords,  \
+                           ctx->d_gamma_prog, (const int32_t* const*)ctx->d_prog_code, (const int32_t*)ctx->d_prog_len,         \
+                           (const double* const*)ctx->d_prog_consts, (const int32_t*)ctx->d_prog_nconsts, n_regs, ccap,        \
+                           ctx->d_fmat, ctx->d_fvec);                                                                          \
+    } while (0)
+        // measured on MI355X (cube64: 12 288 facets x 36 points; square512: 1 024 facets x 6 points): 3 points per lane and 16
+        // lanes per facet in 3D (258 -> 170 us vs one point per lane), one point per lane in 2D
+        if (g.dim == 2) GF_LAUNCH(2, 8, 1, 64, 2);
+        else GF_LAUNCH(3, 16, 3, 64, 2);
+#undef GF_LAUNCH
     }
     FieldPtrs src;
     for (int j = 0; j < 3; ++j) { src.ki[j] = ctx->src_i[j]; src.ke[j] = ctx->src_e[j]; }
