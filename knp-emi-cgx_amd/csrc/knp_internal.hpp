@@ -54,6 +54,7 @@ struct KnpProgram {
     int n_instr = 0, n_consts = 0, n_regs = 0;
     int32_t* d_code = nullptr;
     double* d_consts = nullptr;
+    double* h_consts = nullptr;   // pinned staging copy of the constants (per-step refresh without a synchronisation)
 };
 
 struct knp_ctx;

@@ -1544,7 +1544,7 @@ int knp_destroy(knp_ctx* ctx) {
     if (ctx->h_red) (void)hipHostFree(ctx->h_red);
     if (ctx->h_seq) (void)hipHostFree((void*)ctx->h_seq);
     dev_free(ctx->d_V); dev_free(ctx->d_w); dev_free(ctx->d_t);
-    for (auto& p : ctx->progs) { dev_free(p.d_code); dev_free(p.d_consts); }
+    for (auto& p : ctx->progs) { dev_free(p.d_code); dev_free(p.d_consts); if (p.h_consts) (void)hipHostFree(p.h_consts); }
     dev_free(ctx->d_prog_code); dev_free(ctx->d_prog_consts); dev_free(ctx->d_prog_len); dev_free(ctx->d_prog_nconsts);
     for (int h = 0; h < KNP_MAX_HIER; ++h) {
         KnpAmgHier& H = ctx->hier[h];
@@ -1686,6 +1686,7 @@ int knp_set_program(knp_ctx* ctx, int32_t id, int32_t n_instr, const int32_t* co
     p.n_regs = n_regs;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     dev_free(p.d_code); dev_free(p.d_consts);
+    if (p.h_consts) { (void)hipHostFree(p.h_consts); p.h_consts = nullptr; }
     p.n_instr = n_instr; p.n_consts = n_consts;
     KCHK(dev_upload_raw(ctx, &p.d_code, code, (size_t)4 * n_instr));
     KCHK(dev_upload_raw(ctx, &p.d_consts, consts, (size_t)n_consts));
@@ -1695,8 +1696,15 @@ int knp_set_program(knp_ctx* ctx, int32_t id, int32_t n_instr, const int32_t* co
 int knp_set_program_constants(knp_ctx* ctx, int32_t id, int32_t n_consts, const double* consts) {
     CHECK_CTX(ctx);
     if (id < 0 || id >= (int)ctx->progs.size() || n_consts != ctx->progs[id].n_consts) { ctx->err = "program id / constant count mismatch"; return KNP_E_ARG; }
-    if (n_consts) HIPCHK(hipMemcpyAsync(ctx->progs[id].d_consts, consts, n_consts * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));  // consts is a caller-owned pageable buffer
+    if (n_consts) {
+        // staged through a pinned buffer of the ctx: the copy is stream-ordered and the caller's (pageable) buffer is free
+        // on return -- no synchronisation in the per-step path.  A second update before the first copy ran would only
+        // make that copy carry the newer values.
+        KnpProgram& pr = ctx->progs[id];
+        if (!pr.h_consts) HIPCHK(hipHostMalloc((void**)&pr.h_consts, n_consts * sizeof(double), hipHostMallocDefault));
+        std::memcpy(pr.h_consts, consts, n_consts * sizeof(double));
+        HIPCHK(hipMemcpyAsync(pr.d_consts, pr.h_consts, n_consts * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    }
     return KNP_OK;
 }
 static int sync_program_table(knp_ctx* ctx) {
