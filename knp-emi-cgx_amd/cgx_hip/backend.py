@@ -108,6 +108,7 @@ class Backend:
             self.p2p_setup()
         if getattr(problem, "programs", None):
             self.upload_programs()
+        self.set_sources()
         self.setup_deflation()
         self.setup_dirichlet()
 
@@ -358,6 +359,23 @@ class Backend:
         De = np.array([float(ion["De"].value) for ion in p.ion_list], dtype=np.float64)
         self.check(self.lib.knp_set_params(self.ctx, float(p.dt.value), float(p.F.value), float(p.C_M.value),
                                            float(p.psi.value), len(p.ion_list), _f64(z), _f64(Di), _f64(De)))
+
+    def set_sources(self):
+        """Volume source functions f_i / f_e of the ion table (``source_terms: ion_injection``); Constants are the
+        reference's zero placeholders."""
+        from .fem import Function
+        fi = (C.c_void_p * 3)()
+        fe = (C.c_void_p * 3)()
+        self._src_keep = []
+        for j, ion in enumerate(self.p.ion_list[:3]):
+            for arr, key in ((fi, "f_i"), (fe, "f_e")):
+                f = ion.get(key)
+                if isinstance(f, Function):
+                    arr[j] = f.data_ptr()
+                    self._src_keep.append(f)
+                elif f is not None and float(getattr(f, "value", 0.0)) != 0.0:
+                    raise NotImplementedError("constant non-zero volume sources: pass a Function (nodal values) instead")
+        self.check(self.lib.knp_set_sources(self.ctx, fi, fe))
 
     def upload_programs(self):
         for pid, spec in self.p.programs.items():

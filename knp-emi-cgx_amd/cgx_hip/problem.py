@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import collections.abc
 import ctypes as C
+import math
 import os
 import pathlib
 import time
@@ -177,8 +178,8 @@ class MixedDimensionalProblem(ABC):
             raise NotImplementedError("dirichlet_bcs without MMS_test is not supported yet by the MI355X-native path; "
                                       "the hot path implements the pure-Neumann case (null-space gauge).")
         self.source_terms = config.get("source_terms", None)
-        if self.source_terms is not None:
-            raise NotImplementedError("source_terms are not supported yet by the MI355X-native path (SURVEY 8f-3).")
+        if self.source_terms not in (None, "ion_injection"):
+            raise RuntimeError(f"Unknown source_terms '{self.source_terms}' (the reference knows 'ion_injection').")
         self.point_evaluation = False
         self.gamma_points = None
 
@@ -482,8 +483,53 @@ class ProblemKNPEMI(MixedDimensionalProblem):
             self.bc_values.append(self.M.evaluate(self.exact_sols["phi_e"], xb, float(self.t.value)))
             self.bcs = [("extra", f, self.bc_vertices, self.bc_values[f]) for f in range(self.num_variables)]
 
+    # ---- ion injection (mixed_dim_problem.py:467-541, 806-811; KNPEMIx_problem.py:200-218)
+    def get_min_and_max_coordinates(self):
+        x = self.local_mesh.coords
+        out = []
+        for a in range(x.shape[1]):
+            out += [-self.comm.allreduce_max(-x[:, a].min()), self.comm.allreduce_max(x[:, a].max())]
+        return out
+
+    def calculate_mesh_center(self):
+        mm = self.get_min_and_max_coordinates()
+        c = [(mm[2 * a] + mm[2 * a + 1]) / 2 for a in range(len(mm) // 2)]
+        return np.array(c + [0.0] * (3 - len(c)))
+
+    def initialize_injection_site(self, delta: float):
+        """Cells with every vertex inside the cube of half-width delta around the mesh centre, and their volume."""
+        lm = self.local_mesh
+        x = np.zeros((lm.coords.shape[0], 3))
+        x[:, :lm.coords.shape[1]] = lm.coords
+        c = self.calculate_mesh_center()
+        self.x_L, self.y_L, self.z_L = c - delta
+        self.x_U, self.y_U, self.z_U = c + delta
+        tol = 1e-14
+        inside = ((x >= (c - delta) - tol) & (x <= (c + delta) + tol)).all(axis=1)
+        self.injection_cells = np.nonzero(inside[lm.cells].all(axis=1))[0]
+        d = lm.coords.shape[1]
+        X = lm.coords[lm.cells]
+        vol = np.abs(np.linalg.det(X[:, 1:, :] - X[:, :1, :])) / math.factorial(d)
+        owned = self.injection_cells[self.injection_cells < lm.n_cells_owned]
+        self.injection_volume = self.comm.allreduce_sum(float(vol[owned].sum()))
+
     def setup_source_terms(self):
-        raise NotImplementedError
+        """K and Cl are injected into the extracellular space at 5 nA (KNPEMIx_problem.py:200-218)."""
+        mm = self.get_min_and_max_coordinates()
+        self.initialize_injection_site(delta=(mm[1] - mm[0]) / 10)
+        if not self.injection_volume > 0:
+            raise RuntimeError("ion_injection: no mesh cell lies inside the injection site")
+        I = 5e-9
+        src_term = I / (1 * float(self.F.value)) / self.injection_volume
+        verts = np.unique(self.local_mesh.cells[self.injection_cells])
+        for idx in (1, 2):
+            f = fem.Function(self.V, name=f"f_e_{self.ion_list[idx]['name']}")
+            arr = np.zeros(self.local_mesh.coords.shape[0])
+            arr[verts] = src_term
+            f.x.array[:] = torch.as_tensor(arr, dtype=f.x.array.dtype, device=f.x.array.device)
+            self.ion_list[idx]["f_e"] = f
+        if getattr(self, "backend", None) is not None:
+            self.backend.set_sources()
 
     # ---- initial conditions (KNPEMIx_problem.py:326-353, 386-452)
     def set_initial_conditions(self):

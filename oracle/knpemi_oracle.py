@@ -576,6 +576,26 @@ class OracleKNPEMI:
         return I
 
     # ---- right-hand side (KNPEMIx_problem.py:600-614,641-642)
+    def set_ion_injection(self, current=5e-9):
+        """``source_terms: ion_injection`` (src/CGx/utils/mixed_dim_problem.py:467-541, 806-811 and
+        src/CGx/KNPEMI/KNPEMIx_problem.py:200-218): K and Cl sources f_e = I/(F vol) on the vertices of the
+        cells that lie inside the cube of half-width (x_max - x_min)/10 around the mesh centre."""
+        x = np.zeros((self.coords.shape[0], 3))
+        x[:, :self.dim] = self.coords
+        lo, hi = self.coords.min(axis=0), self.coords.max(axis=0)
+        c = np.zeros(3)
+        c[:self.dim] = (lo + hi) / 2
+        delta = (hi[0] - lo[0]) / 10
+        tol = 1e-14
+        inside = ((x >= c - delta - tol) & (x <= c + delta + tol)).all(axis=1)
+        cells = np.nonzero(inside[self.cells].all(axis=1))[0]
+        X = self.coords[self.cells[cells]]
+        vol = (np.abs(np.linalg.det(X[:, 1:, :] - X[:, :1, :])) / math.factorial(self.dim)).sum()
+        self.injection_cells, self.injection_volume = cells, vol
+        f = np.zeros(self.coords.shape[0])
+        f[np.unique(self.cells[cells])] = current / self.p.F / vol
+        self.f_e = [None, f, f.copy()]
+
     def assemble_b(self):
         p = self.p
         dt, F, C_M = p.dt, p.F, p.C_M
@@ -584,6 +604,12 @@ class OracleKNPEMI:
             kj = np.where(self.cell_side[:, None] == 0, self.k[0][j][self.cells], self.k[1][j][self.cells])
             loc = np.einsum("cab,cb->ca", self.Mloc, kj)
             np.add.at(b, 4 * self.cnode + j, loc)
+        for j, fj in enumerate(getattr(self, "f_e", None) or []):       # L += dt * f_e * v dx_e (KNPEMIx_problem.py:614)
+            if fj is None:
+                continue
+            ext = self.cell_side == 1
+            loc = np.einsum("cab,cb->ca", self.Mloc[ext], fj[self.cells[ext]])
+            np.add.at(b, 4 * self.cnode[ext] + j, dt * loc)
         Iq = self.channel_currents_q()
         Itot = Iq.sum(axis=0)
         phim = self._at_q(self.phi_m)
