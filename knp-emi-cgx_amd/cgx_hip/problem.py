@@ -174,9 +174,6 @@ class MixedDimensionalProblem(ABC):
                 self.dim = int(config["MMS_test"]["dim"])
             except Exception:
                 raise RuntimeError('For MMS test, provide dimension "dim" in input file.')
-        elif self.dirichlet_bcs:
-            raise NotImplementedError("dirichlet_bcs without MMS_test is not supported yet by the MI355X-native path; "
-                                      "the hot path implements the pure-Neumann case (null-space gauge).")
         self.source_terms = config.get("source_terms", None)
         if self.source_terms not in (None, "ion_injection"):
             raise RuntimeError(f"Unknown source_terms '{self.source_terms}' (the reference knows 'ion_injection').")
@@ -482,6 +479,28 @@ class ProblemKNPEMI(MixedDimensionalProblem):
             self.bc_values = [self.M.evaluate(self.exact_sols[f"{ion['name']}_e"], xb, float(self.t.value)) for ion in self.ion_list]
             self.bc_values.append(self.M.evaluate(self.exact_sols["phi_e"], xb, float(self.t.value)))
             self.bcs = [("extra", f, self.bc_vertices, self.bc_values[f]) for f in range(self.num_variables)]
+        elif self.dirichlet_bcs:
+            # KNPEMIx_problem.py:135-160: on the exterior boundary every field keeps its initial value (intracellular
+            # fields only where an intracellular cell touches the boundary): k_init, phi_i = phi_m_init, phi_e = 0
+            lm = self.local_mesh
+            if str(getattr(lm, "description", "")).startswith("generated") or self.comm.size > 1:
+                if not str(getattr(lm, "description", "")).startswith("generated"):
+                    raise NotImplementedError("dirichlet_bcs on a partitioned mesh file: only the generated box meshes are supported")
+                mm = self.get_min_and_max_coordinates()
+                x = lm.coords
+                scale = max(mm[2 * a + 1] - mm[2 * a] for a in range(x.shape[1]))
+                on = np.zeros(x.shape[0], dtype=bool)
+                for a in range(x.shape[1]):
+                    on |= (np.abs(x[:, a] - mm[2 * a]) <= 1e-12 * scale) | (np.abs(x[:, a] - mm[2 * a + 1]) <= 1e-12 * scale)
+                self.bc_vertices = np.nonzero(on)[0].astype(np.int32)
+            else:
+                fverts, _, _ = meshmod.exterior_facets(lm.cells)
+                self.bc_vertices = np.unique(fverts).astype(np.int32)
+            nb = len(self.bc_vertices)
+            for side, sfx, phi0 in (("intra", "i", float(self.phi_m_init.value)), ("extra", "e", 0.0)):
+                for f, ion in enumerate(self.ion_list):
+                    self.bcs.append((side, f, self.bc_vertices, np.full(nb, float(ion[f"k{sfx}_init"].value))))
+                self.bcs.append((side, self.N_ions, self.bc_vertices, np.full(nb, phi0)))
 
     # ---- ion injection (mixed_dim_problem.py:467-541, 806-811; KNPEMIx_problem.py:200-218)
     def get_min_and_max_coordinates(self):

@@ -2341,6 +2341,15 @@ int knp_pc_setup(knp_ctx* ctx, int32_t kind) {
 }
 
 // z = M^{-1} r, then (optionally) gauge projection.  cnt = global number of potential DoFs.
+// Dirichlet rows of A are identity rows: the preconditioner must act as the identity there
+__global__ void __launch_bounds__(NT) k_bc_copy(int n_bc, const int32_t* __restrict__ bc_dofs, const double* __restrict__ src,
+                                                double* __restrict__ dst, int phi_only) {
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= n_bc) return;
+    const int d = bc_dofs[i];
+    if (!phi_only || (d & 3) == 3) dst[d] = src[d];
+}
+
 static int pc_apply_proj(knp_ctx* ctx, const double* r, double* z, int64_t cnt) {
     const int dm = ctx->defl_m;
     if (dm > 0) {   // coarse sums of the input residual (before r is possibly overwritten)
@@ -2379,6 +2388,8 @@ static int pc_apply_proj(knp_ctx* ctx, const double* r, double* z, int64_t cnt) 
                     case 16: hipLaunchKernelGGL((k_phi_rhs<16>), dim3(nblocks((int64_t)g.n_nodes_owned * 16)), dim3(NT), 0, ctx->stream, g.n_nodes_owned, ctx->z[0], ctx->z[1], ctx->z[2], ctx->d_pair_ptr, ctx->d_pair_col, ctx->d_pair_M, r, z, ctx->d_t2); break;
                     default: hipLaunchKernelGGL((k_phi_rhs<32>), dim3(nblocks((int64_t)g.n_nodes_owned * 32)), dim3(NT), 0, ctx->stream, g.n_nodes_owned, ctx->z[0], ctx->z[1], ctx->z[2], ctx->d_pair_ptr, ctx->d_pair_col, ctx->d_pair_M, r, z, ctx->d_t2); break;
                 }
+                if (ctx->n_bc > 0)   // pinned potentials: no Schur coupling, their right-hand side is the residual itself
+                    hipLaunchKernelGGL(k_bc_copy, dim3(nblocks(ctx->n_bc)), dim3(NT), 0, ctx->stream, ctx->n_bc, ctx->d_bc_dofs, r, ctx->d_t2, 1);
                 double* w = amg_vcycle(ctx, ctx->hier[1], 0, ctx->d_t2, ctx->d_w2);
                 hipLaunchKernelGGL(k_schur_fin, dim3(nblocks(g.n_nodes_owned)), dim3(NT), 0, ctx->stream, g.n_nodes_owned, ctx->d_cc, ctx->d_t2, w, z);
                 break;
@@ -2387,6 +2398,8 @@ static int pc_apply_proj(knp_ctx* ctx, const double* r, double* z, int64_t cnt) 
                 HIPCHK(hipMemcpyAsync(z, r, (size_t)ctx->n_dof_owned * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
                 break;
         }
+        if (ctx->n_bc > 0 && (ctx->pc_kind == KNP_PC_AMG || ctx->pc_kind == KNP_PC_AMG_BT))
+            hipLaunchKernelGGL(k_bc_copy, dim3(nblocks(ctx->n_bc)), dim3(NT), 0, ctx->stream, ctx->n_bc, ctx->d_bc_dofs, r, z, 0);
         HIPCHK(hipGetLastError());
     }
     if (dm > 0) {

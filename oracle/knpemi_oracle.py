@@ -672,6 +672,74 @@ class OracleKNPEMI:
         return self.l2_norm(self.phi[0], 0), self.l2_norm(self.phi[1], 1)
 
     # ---- time loop (KNPEMIx_solver.py:337-468)
+    # class defaults of the reference's constants (KNPEMIx_problem.py:941-951)
+    REF_DEFAULT_KI, REF_DEFAULT_KE, REF_DEFAULT_PHI_M = (10.0, 130.0, 5.0), (145.0, 3.0, 134.0), -0.070
+
+    def dirichlet_initial_values(self, boundary_vertices, ki=None, ke=None, phi_m=None):
+        """Dirichlet data of the reference's non-MMS branch (KNPEMIx_problem.py:135-160): on the exterior boundary
+        every field keeps an 'initial' value (concentrations k_init, phi_i = phi_m_init, phi_e = 0).  Reference quirk:
+        the BC functions are filled when the problem is CONSTRUCTED, i.e. before set_initial_conditions() copies the
+        config's initial_conditions into the constants, so the values are the class defaults (REF_DEFAULT_*)."""
+        p = self.p
+        ki = self.REF_DEFAULT_KI if ki is None else ki
+        ke = self.REF_DEFAULT_KE if ke is None else ke
+        phi_m = self.REF_DEFAULT_PHI_M if phi_m is None else phi_m
+        dofs, vals = [], []
+        for side, nodes, kinit, phi0 in ((0, self.lay.node_i, ki, phi_m), (1, self.lay.node_e, ke, 0.0)):
+            nb = nodes[boundary_vertices]
+            nb = nb[nb >= 0]
+            for j in range(3):
+                dofs.append(4 * nb + j); vals.append(np.full(len(nb), kinit[j]))
+            dofs.append(4 * nb + 3); vals.append(np.full(len(nb), phi0))
+        return np.concatenate(dofs), np.concatenate(vals)
+
+    def run_dirichlet(self, time_steps, bc_dofs, bc_vals, solver="lu", pc=None, rtol=1e-9, max_it=5000):
+        """Time loop with Dirichlet rows (no null space, KNPEMIx_solver.py:380,415).
+        solver 'lu': sparse LU of the reduced system (DOLFINx zeroes row and column and lifts; row replacement gives the
+        same solution).  solver 'gmres': the PETSc-style GMRES(30) on the row-replaced system with the preconditioner
+        built by ``pc(P_with_identity_rows)``; the preconditioner acts as the identity on the Dirichlet rows."""
+        keep = np.ones(self.n_dof, dtype=bool); keep[bc_dofs] = False
+        idx = np.nonzero(keep)[0]
+        g = np.zeros(self.n_dof); g[bc_dofs] = bc_vals
+        its = []
+
+        def rowrep(A):
+            A = A.tocsr().copy()
+            for d in bc_dofs:                                  # zero the row, unit diagonal
+                A.data[A.indptr[d]:A.indptr[d + 1]] = 0.0
+            A = A + sp.csr_matrix((np.ones(len(bc_dofs)), (bc_dofs, bc_dofs)), shape=A.shape)
+            A.eliminate_zeros()
+            return A.tocsr()
+        M = None
+        if solver == "gmres":
+            M0 = pc(rowrep(self.assemble_P()))
+
+            def M(r):
+                z = M0(r)
+                z[bc_dofs] = r[bc_dofs]
+                return z
+            x = self.pack()
+            x[bc_dofs] = bc_vals
+        for step in range(1, time_steps + 1):
+            self.t += self.p.dt
+            for mdl in self.models:
+                if mdl.kind == "hh":
+                    self.update_t_mod()
+                    self.update_gating(mdl)
+            A = self.assemble_A().tocsr()
+            b = self.assemble_b()
+            if solver == "gmres":
+                Ar = rowrep(A)
+                b[bc_dofs] = bc_vals
+                x, it, _ = gmres_left(Ar, b, x, M, ns=None, rtol=rtol, max_it=max_it)
+                its.append(it)
+            else:
+                x = g.copy()
+                x[idx] = spla.splu(A[idx][:, idx].tocsc()).solve((b - A @ g)[idx])
+            self.unpack(x)
+        self.dirichlet_iterations = its
+        return x
+
     def run(self, time_steps, solver="lu_gauge", pc=None, rtol=1e-9, max_it=5000, log=None):
         """solver: 'lu_gauge' (sparse LU, l2 gauge of the iterative path),
         'lu_pin' (sparse LU with one potential DoF pinned to 0 - a MUMPS-like gauge),
@@ -883,7 +951,7 @@ def pc_amg_vcycle(levels, coarse_inv, pre=1, post=1, cheby_degree=2):
     return lambda r: cycle(0, r)
 
 
-def pc_btcc(o, hier_k, hier_p, pre=1, post=1, cheby_degree=2):
+def pc_btcc(o, hier_k, hier_p, pre=1, post=1, cheby_degree=2, bc_dofs=None):
     """NumPy restatement of the library's block lower-triangular preconditioner (KNP_PC_AMG_BT):
         z_k   = V_k r                                         (V-cycle of the ion-field hierarchy)
         t_phi = r_phi - sum_j z_j r_kj + M (sum_j z_j z_kj)   (== r_phi - A_{phi,k} z_k for exact ion solves,
@@ -914,6 +982,9 @@ def pc_btcc(o, hier_k, hier_p, pre=1, post=1, cheby_degree=2):
         zk = sum(zz[j] * z[j::4] for j in range(3))
         t = np.zeros_like(r)
         t[pidx] = r[pidx] - zr + Mn @ zk
+        if bc_dofs is not None:                 # pinned potentials: no Schur coupling (library: k_bc_copy)
+            bp = bc_dofs[bc_dofs % 4 == 3]
+            t[bp] = r[bp]
         w = Vp(t)
         z[pidx] = w[pidx] + cc * t[pidx]
         return z

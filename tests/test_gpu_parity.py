@@ -306,3 +306,44 @@ def test_mesh_validation_in_knp_create():
     rc = lib.knp_create(C.byref(ctx), C.byref(d))
     assert rc == -5 and b"degenerate" in lib.knp_last_error(ctx)
     lib.knp_destroy(ctx)
+
+
+@pytest.mark.parametrize("kind,N,pc", [("square", 16, "btcc"), ("square", 16, "hypre"), ("cube", 6, "btcc")])
+def test_dirichlet_bcs_without_mms(kind, N, pc):
+    """``dirichlet_bcs: True`` outside MMS runs (KNPEMIx_problem.py:135-160): all fields pinned on the exterior boundary,
+    no null space.  The reference fills the BC functions at construction time, i.e. with the class-default initial
+    values; the config below uses those defaults as initial conditions too, so the data are consistent.
+
+    Checked against the oracle running the SAME algorithm (GMRES(30), preconditioned-norm stopping rule, the same
+    hierarchies): with every extracellular field pinned, "charge the membrane from the intracellular bulk" is a mode
+    on which the block-diagonal P (the reference's preconditioner form) is ~1e7 times weaker than A^-1, so that
+    stopping rule accepts iterates that are still 1e-4 away from the LU solution -- with hypre as with this AMG."""
+    import knpemi_oracle as K
+    cfg = ci_config(N=N, steps=2, rtol=1e-11, kind=kind, pc=pc)
+    cfg["dirichlet_bcs"] = True
+    cfg["initial_conditions"].update({"Na_i": 10, "Na_e": 145, "K_i": 130, "K_e": 3, "Cl_i": 5, "Cl_e": 134})
+    cfg["solver"]["ksp_settings"]["amg_fp32"] = False
+    s = run_native(cfg)
+    assert all(r > 0 for r in s.reasons)
+    params = K.Params(ki_init=K.OracleKNPEMI.REF_DEFAULT_KI, ke_init=K.OracleKNPEMI.REF_DEFAULT_KE)
+    o = (K.make_square if kind == "square" else K.make_cube)(N, models=K.CI_MODELS(), params=params)
+    x = o.coords / o.coords.max()
+    bv = np.nonzero(np.any((np.abs(x) < 1e-12) | (np.abs(x - 1.0) < 1e-12), axis=1))[0]
+    dofs, vals = o.dirichlet_initial_values(bv)
+    assert len(dofs) == 4 * len(bv)                      # the intracellular box does not touch the boundary
+    assert set(dofs.tolist()) == set(s.backend.bc_dofs.cpu().numpy().tolist())
+
+    def fac(P):                       # the hierarchies are data: the ones the host setup built for the library
+        if pc == "btcc":
+            hk, hp = s.hierarchies
+            return K.pc_btcc(o, hk, hp, s.amg_pre, s.amg_post, s.amg_cheby_degree, bc_dofs=dofs)
+        h = s.hierarchy
+        return K.pc_amg_vcycle(h.levels, h.coarse_inv, s.amg_pre, s.amg_post, s.amg_cheby_degree)
+    xo = o.run_dirichlet(2, dofs, vals, solver="gmres", pc=fac, rtol=1e-11)
+    assert o.dirichlet_iterations == list(s.iterations)
+    xn = s.backend.x.cpu().numpy()
+    for f in range(4):
+        assert np.max(np.abs(xn[f::4] - xo[f::4])) <= 1e-9 * np.max(np.abs(xo[f::4])), f
+    # boundary values really are the pinned ones
+    p = s.problem
+    assert np.allclose(p.wh[1][0].numpy()[bv], 145.0) and np.allclose(p.wh[1][3].numpy()[bv], 0.0)
