@@ -866,6 +866,44 @@ static void launch_spmv_mp(hipStream_t st, int lanes, int n_rows, const int32_t*
     else launch_spmv_t<MODE, 0, double>(st, lanes, n_rows, rp, ci, v, x, b, y);
 }
 
+// Restriction fused with the first Chebyshev step of the coarse level (zero initial guess):
+//   b_c = R r ;  d_c = x_c = (1/theta_c) D_c^-1 b_c       -- one launch instead of two on every level of every cycle
+template <int L, typename VT>
+__global__ void __launch_bounds__(NT)
+k_restrict_first(int n_rows, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci, const VT* __restrict__ v,
+                 const double* __restrict__ x, double* __restrict__ y, double c, const double* __restrict__ dinv,
+                 double* __restrict__ d, double* __restrict__ xo) {
+    const int gid = blockIdx.x * NT + threadIdx.x;
+    const int row = gid / L;
+    const int lane = threadIdx.x & (L - 1);
+    double s = 0.0;
+    if (row < n_rows) {
+        const int e = rp[row + 1];
+        for (int k = rp[row] + lane; k < e; k += L) s += (double)v[k] * x[ci[k]];
+    }
+#pragma unroll
+    for (int o = L >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, L);
+    if (lane == 0 && row < n_rows) {
+        y[row] = s;
+        const double t = c * dinv[row] * s;
+        d[row] = t;
+        xo[row] = t;
+    }
+}
+template <typename VT>
+static void launch_restrict_first_t(hipStream_t st, int lanes, int n_rows, const int32_t* rp, const int32_t* ci, const VT* v,
+                                    const double* x, double* y, double c, const double* dinv, double* d, double* xo) {
+    if (n_rows <= 0) return;
+    switch (lanes) {
+        case 2: hipLaunchKernelGGL((k_restrict_first<2, VT>), dim3(nblocks((int64_t)n_rows * 2)), dim3(NT), 0, st, n_rows, rp, ci, v, x, y, c, dinv, d, xo); break;
+        case 4: hipLaunchKernelGGL((k_restrict_first<4, VT>), dim3(nblocks((int64_t)n_rows * 4)), dim3(NT), 0, st, n_rows, rp, ci, v, x, y, c, dinv, d, xo); break;
+        case 8: hipLaunchKernelGGL((k_restrict_first<8, VT>), dim3(nblocks((int64_t)n_rows * 8)), dim3(NT), 0, st, n_rows, rp, ci, v, x, y, c, dinv, d, xo); break;
+        case 16: hipLaunchKernelGGL((k_restrict_first<16, VT>), dim3(nblocks((int64_t)n_rows * 16)), dim3(NT), 0, st, n_rows, rp, ci, v, x, y, c, dinv, d, xo); break;
+        case 32: hipLaunchKernelGGL((k_restrict_first<32, VT>), dim3(nblocks((int64_t)n_rows * 32)), dim3(NT), 0, st, n_rows, rp, ci, v, x, y, c, dinv, d, xo); break;
+        default: hipLaunchKernelGGL((k_restrict_first<64, VT>), dim3(nblocks((int64_t)n_rows * 64)), dim3(NT), 0, st, n_rows, rp, ci, v, x, y, c, dinv, d, xo); break;
+    }
+}
+
 static int pick_lanes(double avg_nnz_per_row) {
     if (avg_nnz_per_row <= 3.0) return 2;
     if (avg_nnz_per_row <= 6.0) return 4;
@@ -2204,7 +2242,8 @@ static inline bool level_comm_on(const knp_ctx* ctx) { return ctx->level_comm !=
 // Chebyshev smoothing sweep of A x = b on one level with ping-pong buffers.  On entry the iterate is in
 // *cur (ignored when zero_guess); the sweep alternates between bufA and bufB and leaves *cur pointing at
 // the buffer that holds the result.
-static void amg_smooth(knp_ctx* ctx, KnpAmgHier& H, int l, const double* b, double** cur, double* bufA, double* bufB, bool zero_guess) {
+static void amg_smooth(knp_ctx* ctx, KnpAmgHier& H, int l, const double* b, double** cur, double* bufA, double* bufB, bool zero_guess,
+                       bool first_done = false) {
     KnpAmgLevel& L = H.lv[l];
     const double lmax = 1.1 * L.lambda_max, lmin = 0.1 * L.lambda_max;  // smoothing interval [0.1, 1.1] * lambda_max
     const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
@@ -2225,7 +2264,8 @@ static void amg_smooth(knp_ctx* ctx, KnpAmgHier& H, int l, const double* b, doub
             launch_cheby(st, L.A_lanes, L.n, L.A_rp, L.A_ci, L.A_v, L.A_vf, L.inv_diag, b, xin, c1, c2, L.d, out);
     };
     if (zero_guess) {
-        hipLaunchKernelGGL(k_cheby_first, dim3(std::min(nblocks(L.n), 2048)), dim3(NT), 0, st, L.n, 1.0 / theta, L.inv_diag, b, L.d, *cur);
+        if (!first_done)   // otherwise the restriction kernel of the finer level already wrote d and *cur
+            hipLaunchKernelGGL(k_cheby_first, dim3(std::min(nblocks(L.n), 2048)), dim3(NT), 0, st, L.n, 1.0 / theta, L.inv_diag, b, L.d, *cur);
     } else {
         double* out = other(*cur);
         step(*cur, 0.0, 1.0 / theta, out);
@@ -2255,7 +2295,7 @@ static int amg_flips(const KnpAmgHier& H, bool last_no_dense) {
 
 // V-cycle on level l for right-hand side b.  The result is written to `want` when non-null (level 0: the
 // caller's z), otherwise to whichever of the level's two buffers the ping-pong ends in; returns that pointer.
-static double* amg_vcycle(knp_ctx* ctx, KnpAmgHier& H, int l, const double* b, double* want) {
+static double* amg_vcycle(knp_ctx* ctx, KnpAmgHier& H, int l, const double* b, double* want, bool first_done = false) {
     hipStream_t st = ctx->stream;
     KnpAmgLevel& L = H.lv[l];
     const bool last = (l == H.levels - 1);
@@ -2272,14 +2312,14 @@ static double* amg_vcycle(knp_ctx* ctx, KnpAmgHier& H, int l, const double* b, d
     double* cur = (flips & 1) ? bufB : bufA;    // start so that the final iterate lands in bufA
     if (last) {  // no coarse inverse supplied: smooth only
         bool zero = true;
-        for (int sw = 0; sw < H.pre + H.post; ++sw) { amg_smooth(ctx, H, l, b, &cur, bufA, bufB, zero); zero = false; }
+        for (int sw = 0; sw < H.pre + H.post; ++sw) { amg_smooth(ctx, H, l, b, &cur, bufA, bufB, zero, zero && first_done); zero = false; }
         if (zero) { hipLaunchKernelGGL(k_fill, dim3(std::min(nblocks(L.n), 2048)), dim3(NT), 0, st, L.n, 0.0, bufA); cur = bufA; }
         return cur;
     }
     KnpAmgLevel& C = H.lv[l + 1];
     const int nc = L.n_coarse;
     bool zero = true;
-    for (int sw = 0; sw < H.pre; ++sw) { amg_smooth(ctx, H, l, b, &cur, bufA, bufB, zero); zero = false; }
+    for (int sw = 0; sw < H.pre; ++sw) { amg_smooth(ctx, H, l, b, &cur, bufA, bufB, zero, zero && first_done); zero = false; }
     if (zero) hipLaunchKernelGGL(k_fill, dim3(std::min(nblocks(L.n), 2048)), dim3(NT), 0, st, L.n, 0.0, cur);
     // r = b - A x ; b_c = R r
     const int hidx = (int)(&H - ctx->hier);
@@ -2290,12 +2330,26 @@ static double* amg_vcycle(knp_ctx* ctx, KnpAmgHier& H, int l, const double* b, d
                         ctx->d_pair_col, ctx->d_p_vals, ctx->d_p_vals_f, L.inv_diag, b, cur, 0.0, 0.0, L.d, L.r);
     else
         launch_spmv_mp<1>(st, L.A_lanes, L.n, L.A_rp, L.A_ci, L.A_v, L.A_vf, cur, b, L.r);
-    launch_spmv_mp<0>(st, L.R_lanes, nc, L.R_rp, L.R_ci, L.R_v, L.R_vf, L.r, nullptr, C.b);
+    // the coarse level starts with a Chebyshev step from a zero guess unless it is the dense solve or has no smoothing
+    // before its own restriction; that step is pointwise in b_c and is fused into the restriction when b_c is complete
+    // after this kernel (no reverse halo / all-reduce to follow)
+    const bool c_last = (l + 1 == H.levels - 1);
+    const bool c_smooths_first = c_last ? (H.nc == 0 && H.pre + H.post > 0) : (H.pre > 0);
+    const bool fuse_first = c_smooths_first && L.repl_n == 0 && !C.dist;
+    if (fuse_first) {
+        const int cflips = amg_flips(H, c_last);
+        double* c_cur = (cflips & 1) ? C.r2 : C.x;          // where the coarse level's ping-pong starts (see below)
+        const double c_theta = 0.5 * (1.1 + 0.1) * C.lambda_max;
+        if (L.R_vf) launch_restrict_first_t<float>(st, L.R_lanes, nc, L.R_rp, L.R_ci, L.R_vf, L.r, C.b, 1.0 / c_theta, C.inv_diag, C.d, c_cur);
+        else launch_restrict_first_t<double>(st, L.R_lanes, nc, L.R_rp, L.R_ci, L.R_v, L.r, C.b, 1.0 / c_theta, C.inv_diag, C.d, c_cur);
+    } else {
+        launch_spmv_mp<0>(st, L.R_lanes, nc, L.R_rp, L.R_ci, L.R_v, L.R_vf, L.r, nullptr, C.b);
+    }
     if (level_comm_on(ctx)) {
         if (L.repl_n > 0) level_exchange(ctx, hidx, l, 2, C.b);           // replicate the coarse rhs
         else if (C.dist) level_exchange(ctx, hidx, l + 1, 1, C.b);        // ghost rows -> owners
     }
-    double* xc = amg_vcycle(ctx, H, l + 1, C.b, nullptr);
+    double* xc = amg_vcycle(ctx, H, l + 1, C.b, nullptr, fuse_first);
     if (C.dist && level_comm_on(ctx) && L.repl_n == 0) level_exchange(ctx, hidx, l + 1, 0, xc);
     // x += P x_c (fused)
     launch_spmv_mp<2>(st, L.P_lanes, L.n, L.P_rp, L.P_ci, L.P_v, L.P_vf, xc, nullptr, cur);
