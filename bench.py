@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--profile-all", action="store_true", help="time every kernel class with HIP events (adds overhead)")
+    ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
+                    help="override a ksp_settings entry (e.g. --set amg_cheby_degree=2); tuning runs only")
     return ap.parse_args()
 
 
@@ -95,6 +97,9 @@ def main():
         problem = make_problem(cfg, models=args.models, local_mesh=lm)
         what = f"{world} x unit {kind} {N}^{2 if kind == 'square' else 3} (BASELINE configs[{1 if kind == 'square' else 2}])"
     problem.solver_config["view_ksp"] = False
+    for kv in args.set:
+        k, v = kv.split("=", 1)
+        problem.solver_config["ksp_settings"][k] = (v.lower() == "true") if v.lower() in ("true", "false") else (float(v) if "." in v or "e" in v.lower() else int(v))
     solver = SolverKNPEMI(problem, solver_config=problem.solver_config)
 
     # ---- run the reference loop, but split into warmup and timed parts -------------------------

@@ -199,6 +199,9 @@ int knp_set_params(knp_ctx* ctx, double dt, double F, double C_M, double psi, in
                    const double* z, const double* Di, const double* De);
 int knp_set_program(knp_ctx* ctx, int32_t prog_id, int32_t n_instr, const int32_t* code /* host [n_instr*4] */,
                     int32_t n_consts, const double* consts /* host */);
+/* "native" when the membrane programs were compiled with hiprtc for this device (knp_jit.cpp), otherwise the reason why the
+ * bytecode interpreter runs (KNP_JIT=0, no libhiprtc, compile log).  Both run on the GPU and give the same values. */
+const char* knp_jit_status(knp_ctx* ctx);
 int knp_set_program_constants(knp_ctx* ctx, int32_t prog_id, int32_t n_consts, const double* consts);
 /* Dirichlet conditions (reference: dfx.fem.dirichletbc + bcs= of assemble_*_block, KNPEMIx_problem.py:106-134,
  * KNPEMIx_solver.py:114-116): rows of the listed owned DoFs become identity rows in A and P at every assembly;

@@ -48,6 +48,9 @@ struct KnpHostGraph {
 };
 
 int knp_build_graph(const knp_mesh_desc* m, KnpHostGraph& g);
+struct knp_ctx;
+void knp_jit_build(knp_ctx* ctx);
+void knp_jit_release(knp_ctx* ctx);
 
 // ---- device-side program ------------------------------------------------------------------
 struct KnpProgram {
@@ -55,6 +58,7 @@ struct KnpProgram {
     int32_t* d_code = nullptr;
     double* d_consts = nullptr;
     double* h_consts = nullptr;   // pinned staging copy of the constants (per-step refresh without a synchronisation)
+    std::vector<int32_t> h_code;  // host copy of the bytecode (source of the run-time compiled kernel, knp_jit.cpp)
 };
 
 struct knp_ctx;
@@ -166,6 +170,10 @@ struct knp_ctx {
     int32_t* d_prog_nconsts = nullptr;
     int prog_regs = 0, prog_len_cap = 0, prog_consts_cap = 0;   // maxima over the programs (LDS sizing of k_gamma_facets)
     size_t gamma_lds_set = 0;
+    // run-time compiled membrane kernel (knp_jit.cpp); null: the interpreter runs
+    void* jit_module = nullptr;
+    void* jit_fn[2] = {nullptr, nullptr};   // [0] 2D, [1] 3D right-hand-side facet kernel
+    std::string jit_msg;
     bool progs_dirty = true;
     int max_prog = -1;
     // sources

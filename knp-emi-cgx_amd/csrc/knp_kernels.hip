@@ -173,303 +173,9 @@ k_assemble_pairs(int64_t n_pairs, int n_c, DevParams P, const int32_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------
-// membrane-program interpreter (one quadrature point)
+// K2: membrane facet quadrature + the membrane-program interpreter (shared with the run-time compiled variant)
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double powi_d(double x, int e) {
-    bool neg = e < 0;
-    unsigned u = neg ? (unsigned)(-e) : (unsigned)e;
-    double r = 1.0;
-    while (u) {
-        if (u & 1u) r *= x;
-        x *= x;
-        u >>= 1;
-    }
-    return neg ? 1.0 / r : r;
-}
-
-// The register file lives in LDS (a private array indexed by the instruction stream would be spilled to scratch
-// memory): register r of evaluation s of thread t sits at reg[(r*QV + s)*BT + t] -- one column per thread, conflict-free.
-// Each interpreted instruction is executed for QV quadrature points at once: the decode, the branch and the LDS
-// latency are paid once per instruction and the QV independent evaluations overlap.  `code` / `consts` point to LDS
-// when the whole block runs the same program (the usual case), to global memory otherwise.
-// The caller guarantees that every active lane of the wave runs the same program, so the instruction words are
-// wave-uniform: readfirstlane moves them to scalar registers (scalar branch, scalar address arithmetic), and the next
-// instruction is fetched while the current one executes.
-template <int QV, int BT>
-__device__ __forceinline__ void run_program(const int32_t* code, int n_instr, const double* consts,
-                                            const double (*ki)[3], const double (*ke)[3], const double* phim,
-                                            const double (*aux)[KNP_MAX_AUX], const double (*xq)[3], double (*Iout)[3], double* reg) {
-#define RG(i, s) reg[((i) * QV + (s)) * BT]
-#define EACH for (int s_ = 0; s_ < QV; ++s_)
-#define UN(expr)                                                       \
-    _Pragma("unroll") EACH { const double x = RG(a, s_); RG(d, s_) = (expr); } \
-    break
-#define BIN(expr)                                                                             \
-    _Pragma("unroll") EACH { const double x = RG(a, s_), y = RG(b, s_); RG(d, s_) = (expr); } \
-    break
-    int4 nxt = n_instr > 0 ? *reinterpret_cast<const int4*>(code) : make_int4(0, 0, 0, 0);
-    for (int i = 0; i < n_instr; ++i) {
-        const int4 ins = nxt;
-        if (i + 1 < n_instr) nxt = *reinterpret_cast<const int4*>(code + 4 * (i + 1));
-        const int op = __builtin_amdgcn_readfirstlane(ins.x), d = __builtin_amdgcn_readfirstlane(ins.y),
-                  a = __builtin_amdgcn_readfirstlane(ins.z), b = __builtin_amdgcn_readfirstlane(ins.w);
-        switch (op) {
-            case KNP_OP_CONST: { const double c = consts[a];
-#pragma unroll
-                EACH RG(d, s_) = c; } break;
-            case KNP_OP_KI:
-#pragma unroll
-                EACH RG(d, s_) = ki[s_][a]; break;
-            case KNP_OP_KE:
-#pragma unroll
-                EACH RG(d, s_) = ke[s_][a]; break;
-            case KNP_OP_PHIM:
-#pragma unroll
-                EACH RG(d, s_) = phim[s_]; break;
-            case KNP_OP_AUX:
-#pragma unroll
-                EACH RG(d, s_) = aux[s_][a]; break;
-            case KNP_OP_X:
-#pragma unroll
-                EACH RG(d, s_) = xq[s_][a]; break;
-            case KNP_OP_ADD: BIN(x + y);
-            case KNP_OP_SUB: BIN(x - y);
-            case KNP_OP_MUL: BIN(x * y);
-            case KNP_OP_DIV: BIN(x / y);
-            case KNP_OP_NEG: UN(-x);
-            case KNP_OP_POW: BIN(pow(x, y));
-            case KNP_OP_LN: UN(log(x));
-            case KNP_OP_EXP: UN(exp(x));
-            case KNP_OP_SQRT: UN(sqrt(x));
-            case KNP_OP_MAX: BIN(fmax(x, y));
-            case KNP_OP_MIN: BIN(fmin(x, y));
-            case KNP_OP_ABS: UN(fabs(x));
-            case KNP_OP_LT: BIN(x < y ? 1.0 : 0.0);
-            case KNP_OP_GT: BIN(x > y ? 1.0 : 0.0);
-            case KNP_OP_LE: BIN(x <= y ? 1.0 : 0.0);
-            case KNP_OP_GE: BIN(x >= y ? 1.0 : 0.0);
-            case KNP_OP_EQ: BIN(x == y ? 1.0 : 0.0);
-            case KNP_OP_AND: BIN((x != 0.0 && y != 0.0) ? 1.0 : 0.0);
-            case KNP_OP_OR: BIN((x != 0.0 || y != 0.0) ? 1.0 : 0.0);
-            case KNP_OP_NOT: UN(x != 0.0 ? 0.0 : 1.0);
-            case KNP_OP_SEL:
-#pragma unroll
-                EACH { if (RG(a, s_) != 0.0) RG(d, s_) = RG(b, s_); } break;
-            case KNP_OP_OUT:
-#pragma unroll
-                EACH Iout[s_][a] += RG(b, s_); break;
-            case KNP_OP_MOV: UN(x);
-            case KNP_OP_POWI: UN(powi_d(x, b));
-            default: break;
-        }
-    }
-#undef BIN
-#undef UN
-#undef EACH
-#undef RG
-}
-
-// ------------------------------------------------------------------------------------------
-// K2: membrane facet quadrature.  LF lanes per facet; a lane takes the quadrature points q = lane + LF*s, QV of them
-//     at a time; partial sums are combined with a fixed shuffle tree (deterministic).
-//   fmat[(k*NPK + ab)*n_g + g], k = 0..2 intra ions, 3..5 extra ions : M_Gamma[alpha^k C_M/(F z_k)]
-//   fvec[(k*DIM + a)*n_g + g],  k = 0..2 intra, 3..5 extra, 6 potential
-// ------------------------------------------------------------------------------------------
-template <int DIM, bool MAT, bool VEC, int LF, int QV, int BT, int OCC>
-__global__ void __launch_bounds__(BT, OCC)
-k_gamma_facets(int n_g, int n_q, DevParams P, const int32_t* __restrict__ fv, const double* __restrict__ fmeas,
-               const double* __restrict__ qp, const double* __restrict__ qw, FieldPtrs f, int n_aux,
-               const double* __restrict__ coords, const int32_t* __restrict__ gamma_prog,
-               const int32_t* const* __restrict__ prog_code, const int32_t* __restrict__ prog_len,
-               const double* const* __restrict__ prog_consts, const int32_t* __restrict__ prog_nconsts, int n_regs,
-               int consts_cap, double* __restrict__ fmat, double* __restrict__ fvec) {
-    constexpr int NPK = DIM * (DIM + 1) / 2;
-    extern __shared__ double smem[];   // VEC only: [n_regs][QV][BT] register file | [consts_cap] constants | program code
-    const int g_raw = (blockIdx.x * BT + threadIdx.x) / LF;
-    const int qlane = threadIdx.x & (LF - 1);
-    const bool live = g_raw < n_g;
-    const int g = live ? g_raw : n_g - 1;      // idle lanes shadow the last facet so that shuffles stay uniform
-    int v[DIM];
-#pragma unroll
-    for (int a = 0; a < DIM; ++a) v[a] = fv[(size_t)g * DIM + a];
-    double ki[3][DIM], ke[3][DIM], pm[DIM];
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int a = 0; a < DIM; ++a) {
-            ki[j][a] = f.ki[j][v[a]];
-            ke[j][a] = f.ke[j][v[a]];
-        }
-#pragma unroll
-    for (int a = 0; a < DIM; ++a) pm[a] = f.phim[v[a]];
-    const double meas = fmeas[g];
-    double am[MAT ? 6 : 1][MAT ? NPK : 1];
-    double av[VEC ? 7 : 1][VEC ? DIM : 1];
-    if (MAT) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k)
-#pragma unroll
-            for (int i = 0; i < NPK; ++i) am[k][i] = 0.0;
-    }
-    if (VEC) {
-#pragma unroll
-        for (int k = 0; k < 7; ++k)
-#pragma unroll
-            for (int a = 0; a < DIM; ++a) av[k][a] = 0.0;
-    }
-    const int prog = VEC ? gamma_prog[g] : 0;
-    const int32_t* code = nullptr;
-    const double* consts = nullptr;
-    int n_instr = 0;
-    if (VEC) {
-        __shared__ int s_p0;
-        if (threadIdx.x == 0) s_p0 = prog;
-        __syncthreads();
-        const int p0 = s_p0;
-        n_instr = prog_len[prog];
-        if (__syncthreads_and(prog == p0)) {      // one program for the whole block: run it out of LDS
-            double* sconst = smem + (size_t)n_regs * QV * BT;
-            int32_t* scode = reinterpret_cast<int32_t*>(sconst + consts_cap);
-            const int32_t* gc = prog_code[p0];
-            const double* gk = prog_consts[p0];
-            for (int i = threadIdx.x; i < 4 * n_instr; i += BT) scode[i] = gc[i];
-            for (int i = threadIdx.x; i < prog_nconsts[p0]; i += BT) sconst[i] = gk[i];
-            __syncthreads();
-            code = scode;
-            consts = sconst;
-        }   // else: code stays null and every wave walks through its distinct programs one at a time (below)
-    }
-    for (int q0 = qlane; q0 < n_q; q0 += LF * QV) {
-        double lam[QV][DIM], w[QV], kiq[QV][3], keq[QV][3], phq[QV], ali[QV][3], ale[QV][3];
-#pragma unroll
-        for (int s = 0; s < QV; ++s) {
-            const int qq = q0 + s * LF;
-            const bool on = qq < n_q;
-            const int q = on ? qq : q0;               // surplus slots repeat a valid point with weight zero
-#pragma unroll
-            for (int a = 0; a < DIM; ++a) lam[s][a] = qp[q * DIM + a];
-            w[s] = on ? qw[q] * meas : 0.0;
-            phq[s] = 0.0;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                double si = 0.0, se = 0.0;
-#pragma unroll
-                for (int a = 0; a < DIM; ++a) {
-                    si += lam[s][a] * ki[j][a];
-                    se += lam[s][a] * ke[j][a];
-                }
-                kiq[s][j] = si;
-                keq[s][j] = se;
-            }
-#pragma unroll
-            for (int a = 0; a < DIM; ++a) phq[s] += lam[s][a] * pm[a];
-            double deni = 0.0, dene = 0.0;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                deni += P.Di[j] * P.z[j] * P.z[j] * kiq[s][j];
-                dene += P.De[j] * P.z[j] * P.z[j] * keq[s][j];
-            }
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                ali[s][j] = P.Di[j] * P.z[j] * P.z[j] * kiq[s][j] / deni;
-                ale[s][j] = P.De[j] * P.z[j] * P.z[j] * keq[s][j] / dene;
-            }
-            if (MAT) {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const double wi = w[s] * ali[s][j] * P.C_M / (P.F * P.z[j]);
-                    const double we = w[s] * ale[s][j] * P.C_M / (P.F * P.z[j]);
-                    int idx = 0;
-#pragma unroll
-                    for (int a = 0; a < DIM; ++a)
-#pragma unroll
-                        for (int b = a; b < DIM; ++b) {
-                            const double ll = lam[s][a] * lam[s][b];
-                            am[j][idx] += wi * ll;
-                            am[3 + j][idx] += we * ll;
-                            ++idx;
-                        }
-                }
-            }
-        }
-        if (VEC) {
-            double auxq[QV][KNP_MAX_AUX], xq[QV][3], Iout[QV][3];
-#pragma unroll
-            for (int s = 0; s < QV; ++s) {
-                for (int k = 0; k < n_aux; ++k) {
-                    double t = 0.0;
-#pragma unroll
-                    for (int a = 0; a < DIM; ++a) t += lam[s][a] * f.aux[k][v[a]];
-                    auxq[s][k] = t;
-                }
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    double t = 0.0;
-                    if (d < DIM) {
-#pragma unroll
-                        for (int a = 0; a < DIM; ++a) t += lam[s][a] * coords[(size_t)v[a] * DIM + d];
-                    }
-                    xq[s][d] = t;
-                    Iout[s][d] = 0.0;
-                }
-            }
-            double* reg = smem + threadIdx.x;
-            if (code) {
-                run_program<QV, BT>(code, n_instr, consts, kiq, keq, phq, auxq, xq, Iout, reg);
-            } else {   // mixed block: serialise over the programs present in this wave (the interpreter needs uniform code)
-                bool pending = true;
-                while (true) {
-                    const unsigned long long m = __ballot(pending);
-                    if (!m) break;
-                    const int pl = __shfl(prog, __ffsll((long long)m) - 1);
-                    if (pending && prog == pl) {
-                        run_program<QV, BT>(prog_code[pl], prog_len[pl], prog_consts[pl], kiq, keq, phq, auxq, xq, Iout, reg);
-                        pending = false;
-                    }
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < QV; ++s) {
-                const double Itot = Iout[s][0] + Iout[s][1] + Iout[s][2];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const double gi = w[s] * (P.dt * Iout[s][j] - ali[s][j] * P.C_M * phq[s]) / (P.F * P.z[j]);
-                    const double ge = w[s] * (P.dt * Iout[s][j] - ale[s][j] * P.C_M * phq[s]) / (P.F * P.z[j]);
-#pragma unroll
-                    for (int a = 0; a < DIM; ++a) {
-                        av[j][a] += gi * lam[s][a];
-                        av[3 + j][a] += ge * lam[s][a];
-                    }
-                }
-                const double gp = w[s] * (P.dt * Itot - P.C_M * phq[s]) / P.F;
-#pragma unroll
-                for (int a = 0; a < DIM; ++a) av[6][a] += gp * lam[s][a];
-            }
-        }
-    }
-    if (MAT) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k)
-#pragma unroll
-            for (int i = 0; i < NPK; ++i) {
-                double t = am[k][i];
-#pragma unroll
-                for (int o = LF >> 1; o > 0; o >>= 1) t += __shfl_xor(t, o, LF);
-                if (live && qlane == 0) fmat[((size_t)k * NPK + i) * n_g + g] = t;
-            }
-    }
-    if (VEC) {
-#pragma unroll
-        for (int k = 0; k < 7; ++k)
-#pragma unroll
-            for (int a = 0; a < DIM; ++a) {
-                double t = av[k][a];
-#pragma unroll
-                for (int o = LF >> 1; o > 0; o >>= 1) t += __shfl_xor(t, o, LF);
-                if (live && qlane == 0) fvec[((size_t)k * DIM + a) * n_g + g] = t;
-            }
-    }
-}
+#include "knp_gamma_facets.inc"
 
 // ------------------------------------------------------------------------------------------
 // K2b: membrane coupling entries, one thread per membrane vertex pair
@@ -1565,6 +1271,7 @@ int knp_destroy(knp_ctx* ctx) {
     if (!ctx) return KNP_OK;
     (void)hipDeviceSynchronize();
     knp_p2p_free(ctx);
+    knp_jit_release(ctx);
     for (auto& r : ctx->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     dev_free(ctx->d_cells); dev_free(ctx->d_cell_side); dev_free(ctx->d_coords);
     dev_free(ctx->d_node_vertex); dev_free(ctx->d_node_side); dev_free(ctx->d_node_i); dev_free(ctx->d_node_e);
@@ -1726,6 +1433,7 @@ int knp_set_program(knp_ctx* ctx, int32_t id, int32_t n_instr, const int32_t* co
     dev_free(p.d_code); dev_free(p.d_consts);
     if (p.h_consts) { (void)hipHostFree(p.h_consts); p.h_consts = nullptr; }
     p.n_instr = n_instr; p.n_consts = n_consts;
+    p.h_code.assign(code, code + (size_t)4 * n_instr);
     KCHK(dev_upload_raw(ctx, &p.d_code, code, (size_t)4 * n_instr));
     KCHK(dev_upload_raw(ctx, &p.d_consts, consts, (size_t)n_consts));
     ctx->progs_dirty = true;
@@ -1766,7 +1474,14 @@ static int sync_program_table(knp_ctx* ctx) {
     KCHK(dev_upload(ctx, &ctx->d_prog_len, lens));
     KCHK(dev_upload(ctx, &ctx->d_prog_nconsts, ncs));
     ctx->progs_dirty = false;
+    knp_jit_build(ctx);   // native code for the membrane programs when hiprtc is available; else the interpreter runs
     return KNP_OK;
+}
+
+const char* knp_jit_status(knp_ctx* ctx) {
+    if (!ctx) return "";
+    if (ctx->progs_dirty && !ctx->progs.empty()) (void)sync_program_table(ctx);
+    return ctx->jit_msg.c_str();
 }
 
 int knp_set_dirichlet(knp_ctx* ctx, int32_t n, const int32_t* dofs) {
@@ -1836,7 +1551,7 @@ int knp_assemble_matrix(knp_ctx* ctx, const knp_fields* fields) {
                                (const int32_t* const*)nullptr, (const int32_t*)nullptr, (const double* const*)nullptr,
                                (const int32_t*)nullptr, 0, 0, ctx->d_fmat, ctx->d_fvec);
         else
-            hipLaunchKernelGGL((k_gamma_facets<3, true, false, 32, 1, NT, 1>), dim3(nblocks((int64_t)g.n_g * 32)), dim3(NT), 0, ctx->stream, g.n_g, g.n_q, P,
+            hipLaunchKernelGGL((k_gamma_facets<3, true, false, 16, 3, 64, 2>), dim3((unsigned)(((int64_t)g.n_g * 16 + 63) / 64)), dim3(64), 0, ctx->stream, g.n_g, g.n_q, P,
                                ctx->d_fv, ctx->d_fmeas, ctx->d_qp, ctx->d_qw, f, 0, ctx->d_coords, ctx->d_gamma_prog,
                                (const int32_t* const*)nullptr, (const int32_t*)nullptr, (const double* const*)nullptr,
                                (const int32_t*)nullptr, 0, 0, ctx->d_fmat, ctx->d_fvec);
@@ -1927,7 +1642,20 @@ int knp_assemble_rhs(knp_ctx* ctx, const knp_fields* fields, double* b) {
     } while (0)
         // measured on MI355X (cube64: 12 288 facets x 36 points; square512: 1 024 facets x 6 points): 3 points per lane and 16
         // lanes per facet in 3D (258 -> 170 us vs one point per lane), one point per lane in 2D
-        if (g.dim == 2) GF_LAUNCH(2, 8, 1, 64, 2);
+        void* jit = ctx->jit_fn[g.dim == 2 ? 0 : 1];
+        if (jit) {   // run-time compiled programs (knp_jit.cpp): same kernel source, native mechanism code, no LDS register file
+            int n_g = g.n_g, n_q = g.n_q, n_aux_ = n_aux, nr = 0, cc0 = 0;
+            DevParams Pp = P;
+            FieldPtrs ff = f;
+            const int32_t* fv = ctx->d_fv; const double* fmeas = ctx->d_fmeas; const double* qp = ctx->d_qp; const double* qw = ctx->d_qw;
+            const double* coords = ctx->d_coords; const int32_t* gp = ctx->d_gamma_prog;
+            const int32_t* const* pc = (const int32_t* const*)ctx->d_prog_code; const int32_t* pl = ctx->d_prog_len;
+            const double* const* pk = (const double* const*)ctx->d_prog_consts; const int32_t* pn = ctx->d_prog_nconsts;
+            double* fmat = ctx->d_fmat; double* fvec = ctx->d_fvec;
+            void* args[] = {&n_g, &n_q, &Pp, &fv, &fmeas, &qp, &qw, &ff, &n_aux_, &coords, &gp, &pc, &pl, &pk, &pn, &nr, &cc0, &fmat, &fvec};
+            const int L = g.dim == 2 ? 8 : 16;
+            HIPCHK(hipModuleLaunchKernel((hipFunction_t)jit, (unsigned)(((int64_t)g.n_g * L + 63) / 64), 1, 1, 64, 1, 1, 0, ctx->stream, args, nullptr));
+        } else if (g.dim == 2) GF_LAUNCH(2, 8, 1, 64, 2);
         else GF_LAUNCH(3, 16, 3, 64, 2);
 #undef GF_LAUNCH
     }

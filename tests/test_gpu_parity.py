@@ -347,3 +347,28 @@ def test_dirichlet_bcs_without_mms(kind, N, pc):
     # boundary values really are the pinned ones
     p = s.problem
     assert np.allclose(p.wh[1][0].numpy()[bv], 145.0) and np.allclose(p.wh[1][3].numpy()[bv], 0.0)
+
+
+@pytest.mark.parametrize("kind,N", [("square", 16), ("cube", 6)])
+def test_runtime_compiled_membrane_programs_match_interpreter(kind, N, monkeypatch):
+    """The membrane currents run as native code compiled with hiprtc from the uploaded bytecode (csrc/knp_jit.cpp);
+    the bytecode interpreter is the fallback.  Same right-hand side from both, and the native one is the default."""
+    def rhs(jit):
+        monkeypatch.setenv("KNP_JIT", "1" if jit else "0")
+        p = make_problem(ci_config(N=N, steps=1, kind=kind))
+        be = p.create_backend()
+        p.t.value = float(p.dt.value)
+        for m in p.ionic_models:
+            if hasattr(m, "update_t_mod"):
+                m.update_t_mod()
+        be.assemble_matrix()
+        be.assemble_rhs()
+        status = be.lib.knp_jit_status(be.ctx).decode()
+        return be.b.cpu().numpy().copy(), status
+    b_native, st_native = rhs(True)
+    b_interp, st_interp = rhs(False)
+    assert st_native == "native", st_native
+    assert "KNP_JIT=0" in st_interp
+    for f in range(4):
+        scale = np.max(np.abs(b_interp[f::4]))
+        assert np.max(np.abs(b_native[f::4] - b_interp[f::4])) <= 1e-13 * scale, f
