@@ -206,3 +206,55 @@ def test_stacked_generators_equal_global_mesh_on_one_rank():
     c3, t3 = meshmod.create_unit_cube(4)
     assert np.allclose(lm3.coords, c3) and lm3.cells.shape == t3.shape
     assert (lm3.cell_tags == 1).sum() == (meshmod.mark_subdomains_box(c3, t3) == 1).sum()
+
+
+def test_tissue_lattice_generator_and_shared_program():
+    """Tissue surrogate: one tag per cell, membrane tag = cell tag, identical mechanism lists on all tags
+    compile to ONE membrane program; the stimulus area is integrated once."""
+    import numpy as np
+    from cgx_hip import mesh as M
+    from parity_utils import make_problem, tissue_config
+    coords, cells, tags, ft, desc = M.load_mesh("tissue3d_8_2.xdmf", "", 1.0)
+    assert ft == "intra" and "tissue" in desc
+    assert sorted(np.unique(tags).tolist()) == list(range(1, 10))
+    # every cell is a (B-2)^3 block of voxels, 6 tets each
+    counts = np.bincount(tags)[2:]
+    assert np.all(counts == 6 * 2 ** 3)
+    gamma, gtags, _ = M.gamma_integration_entities(cells, tags, tuple(range(2, 10)), (1,), ft)
+    assert np.array_equal(gtags, tags[gamma[:, 0]]) and np.all(tags[gamma[:, 2]] == 1)
+    p = make_problem(tissue_config(2, 16, 2, steps=1), "ci")
+    assert len(p.gamma_tags) == 4 and len(p.programs) == 1
+    assert set(p.tag_program.values()) == {0}
+    assert len(p._stimulus_area_cache) == 1
+
+
+def test_ion_injection_site_and_sources():
+    """source_terms: ion_injection (mixed_dim_problem.py:496-541, KNPEMIx_problem.py:200-218)."""
+    import numpy as np
+    from parity_utils import make_problem, tissue_config
+    cfg = tissue_config(3, 10, 2, steps=1, stimulus=False)
+    cfg["source_terms"] = "ion_injection"
+    p = make_problem(cfg, "passive")
+    h = 1e-6 / 10
+    # the cube of half-width (x_max - x_min)/10 around the centre: 2x2x2 voxels of 6 tets
+    assert len(p.injection_cells) == 48
+    assert abs(p.injection_volume - 8 * h ** 3) <= 1e-12 * h ** 3
+    f = p.ion_list[1]["f_e"].numpy()
+    assert np.count_nonzero(f) == 27 and np.allclose(f[f != 0], 5e-9 / float(p.F.value) / p.injection_volume)
+    assert np.array_equal(f, p.ion_list[2]["f_e"].numpy())
+    assert not hasattr(p.ion_list[0]["f_e"], "numpy")      # Na keeps the zero Constant
+
+
+def test_dirichlet_bc_data_outside_mms():
+    """KNPEMIx_problem.py:135-160: every field pinned on the exterior boundary, values captured at construction
+    (class defaults), intra fields only where an intracellular node exists."""
+    import numpy as np
+    from parity_utils import ci_config, make_problem
+    cfg = ci_config(N=8, steps=1)
+    cfg["dirichlet_bcs"] = True
+    p = make_problem(cfg)
+    assert p.dirichlet_bcs and len(p.bcs) == 8
+    assert len(p.bc_vertices) == 32
+    vals = {(side, f): v[0] for side, f, _, v in p.bcs}
+    assert vals[("extra", 0)] == 145.0 and vals[("extra", 1)] == 3.0 and vals[("extra", 2)] == 134.0 and vals[("extra", 3)] == 0.0
+    assert vals[("intra", 0)] == 10.0 and vals[("intra", 3)] == -0.07
