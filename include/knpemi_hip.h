@@ -202,6 +202,9 @@ int knp_set_program(knp_ctx* ctx, int32_t prog_id, int32_t n_instr, const int32_
 /* "native" when the membrane programs were compiled with hiprtc for this device (knp_jit.cpp), otherwise the reason why the
  * bytecode interpreter runs (KNP_JIT=0, no libhiprtc, compile log).  Both run on the GPU and give the same values. */
 const char* knp_jit_status(knp_ctx* ctx);
+/* test hook, needs neither a device nor a context: generate the HIP source for one program and compile it with hiprtc
+ * for `arch` (e.g. "gfx950"); 0 on success, `log` receives the compiler log or a one-line summary */
+int knp_jit_compile_check(const int32_t* code, int32_t n_instr, const char* arch, char* log, int32_t log_cap);
 int knp_set_program_constants(knp_ctx* ctx, int32_t prog_id, int32_t n_consts, const double* consts);
 /* Dirichlet conditions (reference: dfx.fem.dirichletbc + bcs= of assemble_*_block, KNPEMIx_problem.py:106-134,
  * KNPEMIx_solver.py:114-116): rows of the listed owned DoFs become identity rows in A and P at every assembly;

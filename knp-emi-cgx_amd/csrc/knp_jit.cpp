@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -134,6 +135,88 @@ std::mutex& cache_mutex() {
 
 }  // namespace
 
+// whole translation unit for a set of programs: prelude, one function per program, dispatcher, the facet kernel source
+static bool build_source(const std::vector<KnpProgram>& progs, std::string& out, std::string& err) {
+    std::ifstream in(kernel_source_path());
+    if (!in) { err = "kernel source " + kernel_source_path() + " not found"; return false; }
+    std::stringstream kernel;
+    kernel << in.rdbuf();
+    std::ostringstream src;
+    src << "#define KNP_GAMMA_JIT 1\n#define KNP_MAX_AUX " << KNP_MAX_AUX << "\n"
+        << "typedef int knp_i32_t;\n#define int32_t knp_i32_t\n"
+        << "struct DevParams { double dt, F, C_M, psi; double z[3], Di[3], De[3]; };\n"
+        << "struct FieldPtrs { const double* ki[3]; const double* ke[3]; const double* phim; const double* aux[KNP_MAX_AUX]; };\n"
+        << "__device__ __forceinline__ double powi_d(double x, int e);\n\n";
+    for (size_t i = 0; i < progs.size(); ++i) {
+        if (progs[i].h_code.size() != (size_t)4 * progs[i].n_instr) { err = "program code not retained"; return false; }
+        if (!emit_program(src, (int)i, progs[i])) { err = "unknown opcode"; return false; }
+    }
+    src << "__device__ __forceinline__ void knp_jit_eval(int prog, const double* __restrict__ C, const double* ki, const double* ke, double phim,\n"
+           "                                             const double* aux, const double* xq, double* I) {\n    switch (prog) {\n";
+    for (size_t i = 0; i < progs.size(); ++i)
+        src << "        case " << i << ": knp_prog_" << i << "(C, ki, ke, phim, aux, xq, I); break;\n";
+    src << "        default: break;\n    }\n}\n\n" << kernel.str();
+    out = src.str();
+    return true;
+}
+
+// hiprtc compile (no device needed); code objects are cached per process by (architecture, source)
+static bool compile_source(const std::string& text, const std::string& arch_opt, std::vector<char>& code, std::string& err) {
+    Rtc& R = rtc();
+    if (!R.ok) { err = "libhiprtc not available"; return false; }
+    const std::string key = arch_opt + "\n" + text;
+    {
+        std::lock_guard<std::mutex> lock(cache_mutex());
+        auto it = cache().find(key);
+        if (it != cache().end()) { code = it->second; return true; }
+    }
+    hiprtcProgram prog = nullptr;
+    if (R.create(&prog, text.c_str(), "knp_gamma_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { err = "hiprtcCreateProgram failed"; return false; }
+    const char* opts[] = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off"};
+    const hiprtcResult rc = R.compile(prog, 4, opts);
+    if (rc != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        R.log_size(prog, &n);
+        std::string log(n, '\0');
+        if (n) R.log(prog, &log[0]);
+        err = "hiprtc compile failed: " + log.substr(0, 2000);
+        if (getenv("KNP_JIT_VERBOSE")) fprintf(stderr, "[knp jit] %s\n", err.c_str());
+        R.destroy(&prog);
+        return false;
+    }
+    size_t n = 0;
+    R.code_size(prog, &n);
+    code.resize(n);
+    R.code(prog, code.data());
+    R.destroy(&prog);
+    std::lock_guard<std::mutex> lock(cache_mutex());
+    cache()[key] = code;
+    return true;
+}
+
+// Test hook (no device, no context): does this bytecode become a kernel for `arch` ("gfx950")?  0 on success; the
+// generated source / compiler log is copied to `log`.
+extern "C" int knp_jit_compile_check(const int32_t* code, int32_t n_instr, const char* arch, char* log, int32_t log_cap) {
+    auto say = [&](const std::string& m) {
+        if (log && log_cap > 0) { snprintf(log, (size_t)log_cap, "%s", m.c_str()); }
+    };
+    if (!code || n_instr < 0 || !arch) { say("bad arguments"); return KNP_E_ARG; }
+    KnpProgram p;
+    p.n_instr = n_instr;
+    p.h_code.assign(code, code + (size_t)4 * n_instr);
+    int max_reg = -1;
+    for (int i = 0; i < n_instr; ++i)
+        for (int k = 1; k < 4; ++k) max_reg = std::max(max_reg, code[4 * i + k] < KNP_MAX_PROG_REGS ? code[4 * i + k] : -1);
+    p.n_regs = std::min(max_reg + 1, KNP_MAX_PROG_REGS);
+    std::string src, err;
+    std::vector<KnpProgram> progs(1, p);
+    if (!build_source(progs, src, err)) { say(err); return KNP_E_STATE; }
+    std::vector<char> obj;
+    if (!compile_source(src, std::string("--offload-arch=") + arch, obj, err)) { say(err); return KNP_E_STATE; }
+    say("ok: " + std::to_string(obj.size()) + " bytes of code object");
+    return KNP_OK;
+}
+
 void knp_jit_release(knp_ctx* ctx) {
     if (ctx->jit_module) (void)hipModuleUnload((hipModule_t)ctx->jit_module);
     ctx->jit_module = nullptr;
@@ -147,64 +230,13 @@ void knp_jit_build(knp_ctx* ctx) {
     const char* env = getenv("KNP_JIT");
     if (env && atoi(env) == 0) { ctx->jit_msg = "disabled by KNP_JIT=0"; return; }
     if (ctx->progs.empty()) return;
-    Rtc& R = rtc();
-    if (!R.ok) { ctx->jit_msg = "libhiprtc not available"; return; }
-    std::ifstream in(kernel_source_path());
-    if (!in) { ctx->jit_msg = "kernel source " + kernel_source_path() + " not found"; return; }
-    std::stringstream kernel;
-    kernel << in.rdbuf();
-
-    std::ostringstream src;
-    src << "#define KNP_GAMMA_JIT 1\n#define KNP_MAX_AUX " << KNP_MAX_AUX << "\n"
-        << "typedef int knp_i32_t;\n#define int32_t knp_i32_t\n"
-        << "struct DevParams { double dt, F, C_M, psi; double z[3], Di[3], De[3]; };\n"
-        << "struct FieldPtrs { const double* ki[3]; const double* ke[3]; const double* phim; const double* aux[KNP_MAX_AUX]; };\n"
-        << "__device__ __forceinline__ double powi_d(double x, int e);\n\n";
-    for (size_t i = 0; i < ctx->progs.size(); ++i) {
-        if (ctx->progs[i].h_code.size() != (size_t)4 * ctx->progs[i].n_instr) { ctx->jit_msg = "program code not retained"; return; }
-        if (!emit_program(src, (int)i, ctx->progs[i])) { ctx->jit_msg = "unknown opcode"; return; }
-    }
-    src << "__device__ __forceinline__ void knp_jit_eval(int prog, const double* __restrict__ C, const double* ki, const double* ke, double phim,\n"
-           "                                             const double* aux, const double* xq, double* I) {\n    switch (prog) {\n";
-    for (size_t i = 0; i < ctx->progs.size(); ++i)
-        src << "        case " << i << ": knp_prog_" << i << "(C, ki, ke, phim, aux, xq, I); break;\n";
-    src << "        default: break;\n    }\n}\n\n" << kernel.str();
-
+    std::string src, err;
+    if (!build_source(ctx->progs, src, err)) { ctx->jit_msg = err; return; }
     hipDeviceProp_t prop;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { ctx->jit_msg = "no device properties"; return; }
-    const std::string arch = std::string("--offload-arch=") + prop.gcnArchName;
-    const std::string key = arch + "\n" + src.str();
     std::vector<char> code;
-    {
-        std::lock_guard<std::mutex> lock(cache_mutex());
-        auto it = cache().find(key);
-        if (it != cache().end()) code = it->second;
-    }
-    if (code.empty()) {
-        hiprtcProgram prog = nullptr;
-        const std::string text = src.str();
-        if (R.create(&prog, text.c_str(), "knp_gamma_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { ctx->jit_msg = "hiprtcCreateProgram failed"; return; }
-        const char* opts[] = {arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off"};
-        const hiprtcResult rc = R.compile(prog, 4, opts);
-        if (rc != HIPRTC_SUCCESS) {
-            size_t n = 0;
-            R.log_size(prog, &n);
-            std::string log(n, '\0');
-            if (n) R.log(prog, &log[0]);
-            ctx->jit_msg = "hiprtc compile failed: " + log.substr(0, 2000);
-            if (getenv("KNP_JIT_VERBOSE")) fprintf(stderr, "[knp jit] %s\n", ctx->jit_msg.c_str());
-            R.destroy(&prog);
-            return;
-        }
-        size_t n = 0;
-        R.code_size(prog, &n);
-        code.resize(n);
-        R.code(prog, code.data());
-        R.destroy(&prog);
-        std::lock_guard<std::mutex> lock(cache_mutex());
-        cache()[key] = code;
-    }
+    if (!compile_source(src, std::string("--offload-arch=") + prop.gcnArchName, code, err)) { ctx->jit_msg = err; return; }
     hipModule_t mod = nullptr;
     if (hipModuleLoadData(&mod, code.data()) != hipSuccess) { (void)hipGetLastError(); ctx->jit_msg = "hipModuleLoadData failed"; return; }
     hipFunction_t f2 = nullptr, f3 = nullptr;

@@ -258,3 +258,25 @@ def test_dirichlet_bc_data_outside_mms():
     vals = {(side, f): v[0] for side, f, _, v in p.bcs}
     assert vals[("extra", 0)] == 145.0 and vals[("extra", 1)] == 3.0 and vals[("extra", 2)] == 134.0 and vals[("extra", 3)] == 0.0
     assert vals[("intra", 0)] == 10.0 and vals[("intra", 3)] == -0.07
+
+
+def test_membrane_programs_compile_to_native_code_for_gfx950():
+    """csrc/knp_jit.cpp: the bytecode of the CI mechanism set (and of the glial set) is emitted as HIP source in front of
+    the facet kernel and compiles with hiprtc for gfx950 -- no GPU needed for this check."""
+    import ctypes as C
+    import numpy as np
+    from cgx_hip import _lib
+    from parity_utils import ci_config, make_problem, two_cell_config
+    lib = _lib.load()
+    progs = list(make_problem(ci_config(N=8, steps=1)).programs.values())
+    assert progs and progs[0].code.shape[0] > 50
+    for spec in progs:
+        code = np.ascontiguousarray(spec.code, dtype=np.int32)
+        log = C.create_string_buffer(4096)
+        rc = lib.knp_jit_compile_check(code.ctypes.data_as(C.POINTER(C.c_int32)), code.shape[0], b"gfx950", log, 4096)
+        assert rc == 0, log.value.decode()
+        assert log.value.decode().startswith("ok")
+    # an instruction the code generator does not know is reported, not compiled
+    bad = np.array([[9999, 0, 0, 0]], dtype=np.int32)
+    log = C.create_string_buffer(4096)
+    assert lib.knp_jit_compile_check(bad.ctypes.data_as(C.POINTER(C.c_int32)), 1, b"gfx950", log, 4096) != 0
