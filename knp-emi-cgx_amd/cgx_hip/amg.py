@@ -38,8 +38,9 @@ def strength_graph(A: sp.csr_matrix, theta: float) -> sp.csr_matrix:
     return S
 
 
-def aggregate(S: sp.csr_matrix, seed: int = 0) -> tuple[np.ndarray, int]:
-    """Distance-2 maximal-independent-set aggregation (parallel-friendly Vanek scheme).
+def aggregate(S: sp.csr_matrix, seed: int = 0, distance: int = 2) -> tuple[np.ndarray, int]:
+    """Distance-2 maximal-independent-set aggregation (parallel-friendly Vanek scheme); ``distance=1`` takes the roots
+    from an MIS of S itself: smaller aggregates (slower coarsening, better interpolation).
 
     Roots form an MIS of S^2 (Luby rounds with fixed pseudo-random priorities), every root takes
     its strong neighbours; leftovers join the neighbouring aggregate of highest priority; isolated
@@ -55,12 +56,12 @@ def aggregate(S: sp.csr_matrix, seed: int = 0) -> tuple[np.ndarray, int]:
             break
         w = np.where(und, prio, 0.0)
         m1 = np.maximum(w, _row_max(indptr, w[indices], 0.0))
-        m2 = np.maximum(m1, _row_max(indptr, m1[indices], 0.0))
+        m2 = np.maximum(m1, _row_max(indptr, m1[indices], 0.0)) if distance >= 2 else m1
         new_root = und & (w >= m2)
         state[new_root] = 1
         r = new_root.astype(np.float64)
         r1 = np.maximum(r, _row_max(indptr, r[indices], 0.0))
-        r2 = np.maximum(r1, _row_max(indptr, r1[indices], 0.0))
+        r2 = np.maximum(r1, _row_max(indptr, r1[indices], 0.0)) if distance >= 2 else r1
         state[(state == 0) & (r2 > 0)] = 2
     roots = np.nonzero(state == 1)[0]
     agg = np.full(n, -1, dtype=np.int64)
@@ -105,6 +106,13 @@ def estimate_lambda_max(A: sp.csr_matrix, dinv: np.ndarray, iters: int = 20, see
     return 1.05 * lam
 
 
+def _dist(agg_distance, level):
+    """aggregation distance of a level: an int for all levels or a sequence per level (last entry repeated)"""
+    if isinstance(agg_distance, (list, tuple)):
+        return int(agg_distance[min(level, len(agg_distance) - 1)])
+    return int(agg_distance)
+
+
 class Level:
     __slots__ = ("A", "dinv", "lambda_max", "P", "R")
 
@@ -137,7 +145,7 @@ def restrict_to_fields(P: sp.csr_matrix, fields, block: int = 4) -> sp.csr_matri
 
 
 def build_hierarchy(P: sp.csr_matrix, theta: float = 0.08, max_levels: int = 12, coarse_size: int = 2500,
-                    smooth_prolongator: bool = True) -> Hierarchy:
+                    smooth_prolongator: bool = True, agg_distance=2) -> Hierarchy:
     """Rows with a zero diagonal are inactive: they get no aggregate (zero rows in the prolongator, zero inverse
     diagonal in the smoother), so a field-restricted P yields a hierarchy of that field class only."""
     A = sp.csr_matrix(P, dtype=np.float64)
@@ -156,11 +164,11 @@ def build_hierarchy(P: sp.csr_matrix, theta: float = 0.08, max_levels: int = 12,
         S = strength_graph(A, theta * 0.25 ** len(levels))
         active = diag != 0.0
         if active.all():
-            agg, nagg = aggregate(S, seed=len(levels))
+            agg, nagg = aggregate(S, seed=len(levels), distance=_dist(agg_distance, len(levels)))
             rows_t = np.arange(n)
         else:
             ia = np.nonzero(active)[0]
-            agg, nagg = aggregate(S[ia][:, ia].tocsr(), seed=len(levels))
+            agg, nagg = aggregate(S[ia][:, ia].tocsr(), seed=len(levels), distance=_dist(agg_distance, len(levels)))
             rows_t = ia
         if nagg >= 0.9 * rows_t.size:                         # coarsening stalled
             levels.append(Level(A, dinv, lam))
@@ -186,11 +194,17 @@ def build_hierarchy(P: sp.csr_matrix, theta: float = 0.08, max_levels: int = 12,
         Ac.sort_indices()
         levels.append(Level(A, dinv, lam, Pm, R))
         A = Ac
-    if levels[-1].A.shape[0] <= 6000:
-        coarse_inv = np.linalg.pinv(levels[-1].A.toarray(), rcond=1e-13)
-    else:
-        coarse_inv = None
+    coarse_inv = dense_pseudo_inverse(levels[-1].A) if levels[-1].A.shape[0] <= 6000 else None
     return Hierarchy(levels, coarse_inv)
+
+
+def dense_pseudo_inverse(A: sp.spmatrix) -> np.ndarray:
+    """Pseudo-inverse of the coarsest operator (the potential blocks are singular up to the membrane term).  The
+    Galerkin operators of the symmetric blocks of P are symmetric: the eigenvalue route is 3-4x cheaper than the SVD,
+    which used to be half of the whole host setup; operators with Dirichlet (identity) rows take the general route."""
+    D = A.toarray()
+    sym = np.abs(D - D.T).max() <= 1e-12 * max(np.abs(D).max(), 1e-300)
+    return np.linalg.pinv(D, rcond=1e-13, hermitian=bool(sym))
 
 
 def upload(lib, ctx, check, hier: Hierarchy, pre: int = 1, post: int = 1, cheby_degree: int = 2, index: int = 0):

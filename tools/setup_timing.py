@@ -1,0 +1,24 @@
+"""Developer tool (GPU box): where the one-off setup time goes for a cube<N> workload."""
+import sys, time; sys.path[:0] = ['tests', 'oracle', 'knp-emi-cgx_amd']
+import conftest  # noqa
+import torch
+from parity_utils import ci_config, make_problem
+from cgx_hip.parallel import stacked_cubes_local_mesh
+from cgx_hip import amg, _lib
+from CGx.KNPEMI.KNPEMIx_solver import SolverKNPEMI
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 96
+T = {}
+def tick(name, t0):
+    torch.cuda.synchronize(); T[name] = time.perf_counter() - t0; print(f"{name:28s} {T[name]:7.2f} s", flush=True)
+t = time.perf_counter(); lm = stacked_cubes_local_mesh(N, 1, 0, scale=1e-6); tick("mesh generation", t)
+t = time.perf_counter(); p = make_problem(ci_config(N=N, steps=1, kind="cube", pc="btcc"), local_mesh=lm); tick("problem + programs", t)
+p.solver_config["view_ksp"] = False
+s = SolverKNPEMI(p, solver_config=p.solver_config)
+t = time.perf_counter(); s.setup_solver(); tick("backend (graph build, upload)", t)
+be = s.backend
+t = time.perf_counter(); be.assemble_precond(); P = be.precond_csr(); tick("assemble P + fetch CSR", t)
+t = time.perf_counter(); Pk = amg.restrict_to_fields(P, (0, 1, 2)); Pp = amg.restrict_to_fields(P, (3,)); tick("field restriction", t)
+t = time.perf_counter(); hk = amg.build_hierarchy(Pk, theta=s.amg_theta, coarse_size=s.amg_coarse_size); tick("hierarchy ions", t)
+t = time.perf_counter(); hp = amg.build_hierarchy(Pp, theta=s.amg_theta, coarse_size=s.amg_coarse_size); tick("hierarchy potential", t)
+t = time.perf_counter(); amg.upload(be.lib, be.ctx, be.check, hk, 1, 1, 1, index=0); amg.upload(be.lib, be.ctx, be.check, hp, 1, 1, 1, index=1); tick("upload", t)
+print("n_dof", be.n_dof_owned, "total", sum(T.values()))
