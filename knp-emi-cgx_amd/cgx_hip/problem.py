@@ -502,6 +502,23 @@ class ProblemKNPEMI(MixedDimensionalProblem):
                     self.bcs.append((side, f, self.bc_vertices, np.full(nb, float(ion[f"k{sfx}_init"].value))))
                 self.bcs.append((side, self.N_ions, self.bc_vertices, np.full(nb, phi0)))
 
+        elif self.pin_ecs_potential:
+            # KNPEMIx_problem.py:163-196: phi_e = 0 at one vertex that is not on a membrane.  The reference starts from
+            # vertex 0 and falls back to random picks; here: the non-membrane extracellular vertex of lowest global id.
+            lm = self.local_mesh
+            on_gamma = np.zeros(lm.coords.shape[0], dtype=bool)
+            if lm.gamma.shape[0]:
+                on_gamma[np.unique(self._fv)] = True
+            is_e = np.zeros(lm.coords.shape[0], dtype=bool)
+            is_e[lm.cells[self.cell_side == 1].ravel()] = True
+            cand = np.nonzero(is_e & ~on_gamma & (np.arange(lm.coords.shape[0]) < lm.n_vertices_owned))[0]
+            mine = int(lm.l2g[cand].min()) if cand.size else np.iinfo(np.int64).max
+            best = int(-self.comm.allreduce_max(-float(mine)))
+            verts = cand[lm.l2g[cand] == best].astype(np.int32) if mine == best else np.zeros(0, dtype=np.int32)
+            self.bc_vertices = verts
+            self.bcs = [("extra", self.N_ions, verts, np.zeros(len(verts)))]
+            self.print(f"Phi_e pinned at global vertex {best}")
+
     # ---- ion injection (mixed_dim_problem.py:467-541, 806-811; KNPEMIx_problem.py:200-218)
     def get_min_and_max_coordinates(self):
         x = self.local_mesh.coords

@@ -372,3 +372,22 @@ def test_runtime_compiled_membrane_programs_match_interpreter(kind, N, monkeypat
     for f in range(4):
         scale = np.max(np.abs(b_interp[f::4]))
         assert np.max(np.abs(b_native[f::4] - b_interp[f::4])) <= 1e-13 * scale, f
+
+
+def test_pin_ecs_potential(monkeypatch):
+    """``pin_ecs_potential`` (class switch of the reference, KNPEMIx_problem.py:163-196, :997): phi_e = 0 at one
+    non-membrane vertex instead of the null-space gauge.  Gauge-invariant quantities equal the oracle's."""
+    from CGx.KNPEMI.KNPEMIx_problem import ProblemKNPEMI
+    monkeypatch.setattr(ProblemKNPEMI, "pin_ecs_potential", True)
+    s = run_native(ci_config(N=16, steps=2, rtol=1e-13, pc="btcc"))
+    assert all(r > 0 for r in s.reasons)
+    p = s.problem
+    assert len(p.bc_vertices) == 1 and abs(p.wh[1][3].numpy()[p.bc_vertices[0]]) <= 1e-14
+    o = run_oracle(N=16, steps=2)
+    gam = (o.lay.node_i >= 0) & (o.lay.node_e >= 0)
+    assert np.allclose(p.phi_m_prev.numpy()[gam], o.phi_m[gam], rtol=1e-6)
+    ve = o.lay.node_e >= 0
+    shift = (p.wh[1][3].numpy()[ve] - o.phi[1][ve])
+    assert np.ptp(shift) <= 1e-6 * np.abs(o.phi[0]).max()          # potentials differ by one constant only
+    for j in range(3):
+        assert np.allclose(p.wh[1][j].numpy()[ve], o.k[1][j][ve], rtol=1e-7)
