@@ -203,6 +203,7 @@ class Backend:
 
     # ---- native peer-to-peer exchange (csrc/knp_p2p.hip): rendezvous over torch.distributed, data path in the library
     P2P_FINE, P2P_LEVEL_HALO, P2P_LEVEL_REPL, P2P_SLOTS = 0, 1, 2, 3
+    P2P_SELFTEST_REPS = 8
 
     def _all_ok(self, ok):
         return all(self.p.comm.all_gather_object(bool(ok)))
@@ -248,12 +249,18 @@ class Backend:
         rc = self.lib.knp_p2p_plan_connect(self.ctx, plan.value, handles, 0, None, None, None, None, None, None, None)
         if not self._all_ok(rc == 0):
             return None
-        # self-test: sum of rank-dependent vectors, identical bits on every rank
+        # self-test: sums of rank-dependent vectors, identical bits on every rank; repeated so that both mailbox parities
+        # and back-to-back exchanges are exercised (a flaky visibility problem should show up here, not in a solve)
         n = min(int(n_max), 64)
-        v = torch.arange(n, dtype=torch.float64, device=self.device) * 0.5 + (comm.rank + 1)
-        ref = torch.arange(n, dtype=torch.float64, device=self.device) * 0.5 * comm.size + comm.size * (comm.size + 1) / 2
-        rc = self.lib.knp_p2p_test_allreduce(self.ctx, plan.value, C.c_void_p(v.data_ptr()), n)
-        good = rc == 0 and bool(torch.equal(v, ref))
+        good = True
+        for rep in range(self.P2P_SELFTEST_REPS):
+            base = torch.arange(n, dtype=torch.float64, device=self.device) * 0.5 + rep
+            v = base + (comm.rank + 1)
+            ref = base * comm.size + comm.size * (comm.size + 1) / 2
+            rc = self.lib.knp_p2p_test_allreduce(self.ctx, plan.value, C.c_void_p(v.data_ptr()), n)
+            good = good and rc == 0 and bool(torch.equal(v, ref))
+            if rc != 0:
+                break
         return plan.value if self._all_ok(good) else None
 
     def _p2p_halo_plan(self, h):
@@ -301,9 +308,10 @@ class Backend:
         if not self._all_ok(rc == 0):
             self._p2p_plans[id(h)] = None
             return None
-        # self-test against the torch.distributed exchange of the same halo (forward twice: both mailbox parities)
+        # self-test against the torch.distributed exchange of the same halo, repeated (both mailbox parities,
+        # back-to-back exchanges, forward and reverse interleaved)
         good = True
-        for rep in range(2):
+        for rep in range(self.P2P_SELFTEST_REPS):
             x = torch.zeros(h.n_loc, dtype=torch.float64, device=self.device)
             x[:h.n_own] = torch.arange(h.n_own, dtype=torch.float64, device=self.device) + 1e6 * (me + 1) + rep
             y = x.clone()
@@ -315,6 +323,8 @@ class Backend:
             h.reverse_add(y)
             rc = self.lib.knp_p2p_test_halo(self.ctx, plan.value, C.c_void_p(x.data_ptr()), 1)
             good = good and rc == 0 and bool(torch.allclose(x, y, rtol=1e-13, atol=1e-13))
+            if rc != 0:
+                break
         ok = self._all_ok(good)
         self._p2p_plans[id(h)] = plan.value if ok else None
         self._p2p_keep = getattr(self, "_p2p_keep", []) + [send_idx, recv_idx]
