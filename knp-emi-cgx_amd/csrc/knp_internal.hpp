@@ -75,6 +75,8 @@ struct KnpP2PPlan {
     int64_t send_ptr[KNP_P2P_MAXPEERS + 1], recv_ptr[KNP_P2P_MAXPEERS + 1];
     std::vector<int64_t> remote_fwd_off, remote_rev_off;   // [2*n_peers]: element offset in the peer's data area per parity
     int32_t *d_send_idx = nullptr, *d_recv_idx = nullptr;
+    int64_t n_rev_dst = 0;              // reverse halo: distinct owned entries, their mailbox positions in peer order
+    int32_t *d_rev_dst = nullptr, *d_rev_ptr = nullptr, *d_rev_pos = nullptr;
     unsigned int* d_counter = nullptr;  // "last block done" counters of the pack kernels
     int64_t seq_fwd = 0, seq_rev = 0;   // message sequence numbers (identical on all ranks: calls are collective)
     bool connected = false;

@@ -1,16 +1,16 @@
 // Native peer-to-peer exchange for the multi-GPU path (halo of the Krylov / level vectors before each
-// SpMV, SUM of the inner-product partials).  Replaces the per-exchange Python hook + RCCL call by two kernel launches:
+// SpMV, SUM of the inner-product partials).  Replaces the per-exchange Python hook + RCCL call by ONE kernel launch:
 //
-//   sender    k_p2p_pack      gathers x[send_idx] and stores it straight into the receiver's mailbox (uncached device
-//                             memory of the peer, mapped with hipIpcOpenMemHandle -> xGMI stores between GPUs); the
-//                             last block to finish publishes the message's sequence number to the receiver's flag
-//   receiver  k_p2p_unpack_*  thread 0 of each block waits for the flags (acquire, system scope, bounded by a wall-clock
-//                             timeout), then the block copies / adds the mailbox into the vector
+//   phase 1 (send)     gathers x[send_idx] and stores it straight into the receiver's mailbox (uncached device memory of
+//                      the peer, mapped with hipIpcOpenMemHandle -> xGMI stores between GPUs); the last block to finish
+//                      publishes the message's sequence number to the receiver's flag
+//   phase 2 (receive)  thread 0 of each block waits for the peers' flags (acquire, system scope, bounded by a wall-clock
+//                      timeout), then the block copies / adds its own mailbox into the vector
 //
 // Mailboxes are double buffered by the parity of the sequence number.  Because every neighbour relation is symmetric
 // (both directions are always signalled, also with zero entries) message q+2 cannot overtake the consumption of
-// message q: the sender's own unpack of q+1 needed the receiver's pack of q+1, which the receiver's stream orders
-// after its unpack of q.  The same argument covers the all-reduce (everybody posts to everybody).
+// message q: the sender's own receive phase of q+1 needed the receiver's send phase of q+1, which the receiver's
+// stream orders after its receive phase of q.  The same argument covers the all-reduce (everybody posts to everybody).
 // The all-reduce sums in rank order, so all ranks get bit-identical results (they take the same convergence decisions).
 #include <hip/hip_runtime.h>
 
@@ -73,37 +73,61 @@ __device__ __forceinline__ void p2p_publish(const P2PSend& a, unsigned int* coun
     }
 }
 
-__global__ void __launch_bounds__(P2P_NT) k_p2p_pack(P2PSend a, const int32_t* __restrict__ idx, const double* __restrict__ x,
-                                                     unsigned int* counter, int64_t seq) {
+// ---- one kernel per exchange -----------------------------------------------------------------------------------------
+// Phase 1 writes this rank's data into the peers' mailboxes and (last block) publishes the sequence number; phase 2 waits
+// for the peers' numbers and consumes the own mailbox.  A block may reach phase 2 before the own publish happened: it then
+// only waits for PEERS, whose publish depends on their own phase 1 alone, so there is no circular wait as long as every
+// block of the grid is resident (grids are capped at P2P_MAX_BLOCKS, far below what one GPU holds).
+#define P2P_MAX_BLOCKS 64
+
+__device__ __forceinline__ void p2p_wait_all(const P2PWait& w, int64_t seq, int64_t timeout, int* err, const int* d_err) {
+    if (threadIdx.x == 0)
+        for (int j = 0; j < w.n; ++j) p2p_wait(w.flag[j], seq, timeout, err, d_err);
+    __syncthreads();
+}
+
+// forward halo: ghost entries of x <- owners
+__global__ void __launch_bounds__(P2P_NT) k_p2p_halo_fwd(P2PSend a, P2PWait w, const int32_t* __restrict__ send_idx, int64_t n_ghost,
+                                                         const int32_t* __restrict__ recv_idx, const double* src, double* x,
+                                                         unsigned int* counter, int64_t seq, int64_t timeout, int* err, const int* d_err) {
     const int64_t total = a.ptr[a.n];
     for (int64_t k = (int64_t)blockIdx.x * P2P_NT + threadIdx.x; k < total; k += (int64_t)gridDim.x * P2P_NT) {
         int j = 0;
         while (k >= a.ptr[j + 1]) ++j;
-        a.dst[j][k - a.ptr[j]] = x[idx[k]];
+        a.dst[j][k - a.ptr[j]] = x[send_idx[k]];
     }
     p2p_publish(a, counter, seq);
+    p2p_wait_all(w, seq, timeout, err, d_err);
+    for (int64_t k = (int64_t)blockIdx.x * P2P_NT + threadIdx.x; k < n_ghost; k += (int64_t)gridDim.x * P2P_NT) x[recv_idx[k]] = src[k];
 }
 
-// ghost entries <- mailbox (all peers)
-__global__ void __launch_bounds__(P2P_NT) k_p2p_unpack_fwd(P2PWait w, int64_t seq, int64_t n, const int32_t* __restrict__ idx,
-                                                           const double* src, double* __restrict__ x, int64_t timeout, int* err, const int* d_err) {
-    if (threadIdx.x == 0)
-        for (int j = 0; j < w.n; ++j) p2p_wait(w.flag[j], seq, timeout, err, d_err);
-    __syncthreads();
-    for (int64_t k = (int64_t)blockIdx.x * P2P_NT + threadIdx.x; k < n; k += (int64_t)gridDim.x * P2P_NT) x[idx[k]] = src[k];
+// reverse halo: owned entries of x += the ghost copies the peers hold.  Every owned entry sums its copies in peer order
+// (dst / ptr / pos are built at connect time), so the result does not depend on the order of arrival.
+__global__ void __launch_bounds__(P2P_NT) k_p2p_halo_rev(P2PSend a, P2PWait w, const int32_t* __restrict__ ghost_idx, int64_t n_dst,
+                                                         const int32_t* __restrict__ dst, const int32_t* __restrict__ ptr,
+                                                         const int32_t* __restrict__ pos, const double* src, double* x,
+                                                         unsigned int* counter, int64_t seq, int64_t timeout, int* err, const int* d_err) {
+    const int64_t total = a.ptr[a.n];
+    for (int64_t k = (int64_t)blockIdx.x * P2P_NT + threadIdx.x; k < total; k += (int64_t)gridDim.x * P2P_NT) {
+        int j = 0;
+        while (k >= a.ptr[j + 1]) ++j;
+        a.dst[j][k - a.ptr[j]] = x[ghost_idx[k]];
+    }
+    p2p_publish(a, counter, seq);
+    p2p_wait_all(w, seq, timeout, err, d_err);
+    for (int64_t i = (int64_t)blockIdx.x * P2P_NT + threadIdx.x; i < n_dst; i += (int64_t)gridDim.x * P2P_NT) {
+        double s = 0.0;
+        for (int q = ptr[i]; q < ptr[i + 1]; ++q) s += src[pos[q]];
+        x[dst[i]] += s;
+    }
 }
 
-// owned entries += the ghost copies one peer holds (one launch per peer, in rank order: deterministic sums)
-__global__ void __launch_bounds__(P2P_NT) k_p2p_unpack_rev(const int64_t* flag, int64_t seq, int64_t k0, int64_t k1,
-                                                           const int32_t* __restrict__ idx, const double* src, double* __restrict__ x,
-                                                           int64_t timeout, int* err, const int* d_err) {
-    if (threadIdx.x == 0) p2p_wait(flag, seq, timeout, err, d_err);
-    __syncthreads();
-    for (int64_t k = k0 + (int64_t)blockIdx.x * P2P_NT + threadIdx.x; k < k1; k += (int64_t)gridDim.x * P2P_NT) x[idx[k]] += src[k];
-}
-
-// all-reduce, step 1: my vector -> slot [my rank] of everybody's mailbox (own included)
-__global__ void __launch_bounds__(P2P_NT) k_p2p_ar_post(P2PSend a, int n, const double* __restrict__ v, unsigned int* counter, int64_t seq) {
+// all-reduce: my vector -> slot [my rank] of everybody's mailbox (own included), then out = sum over ranks in rank order
+// (bit-identical on all ranks), optionally mirrored to pinned host memory + sequence word (single-block launches).
+// In place is fine: phase 2 starts after the own flag, i.e. after every block of this rank has read v.
+__global__ void __launch_bounds__(P2P_NT) k_p2p_allreduce(P2PSend a, P2PWait w, int n, const double* v, int64_t stride, const double* src,
+                                                          double* out, double* mirror, volatile int64_t* pub, int64_t pub_val,
+                                                          unsigned int* counter, int64_t seq, int64_t timeout, int* err, const int* d_err) {
     const int64_t total = (int64_t)n * a.n;
     for (int64_t e = (int64_t)blockIdx.x * P2P_NT + threadIdx.x; e < total; e += (int64_t)gridDim.x * P2P_NT) {
         const int r = (int)(e / n);
@@ -111,14 +135,7 @@ __global__ void __launch_bounds__(P2P_NT) k_p2p_ar_post(P2PSend a, int n, const 
         a.dst[r][k] = v[k];
     }
     p2p_publish(a, counter, seq);
-}
-// step 2: out = sum over ranks (rank order), optionally mirrored to pinned host memory + sequence word
-__global__ void __launch_bounds__(P2P_NT) k_p2p_ar_sum(P2PWait w, int64_t seq, int n, int64_t stride, const double* src,
-                                                       double* __restrict__ out, double* mirror, volatile int64_t* pub, int64_t pub_val,
-                                                       int64_t timeout, int* err, const int* d_err) {
-    if (threadIdx.x == 0)
-        for (int j = 0; j < w.n; ++j) p2p_wait(w.flag[j], seq, timeout, err, d_err);
-    __syncthreads();
+    p2p_wait_all(w, seq, timeout, err, d_err);
     for (int k = blockIdx.x * P2P_NT + threadIdx.x; k < n; k += gridDim.x * P2P_NT) {
         double s = 0.0;
         for (int r = 0; r < w.n; ++r) s += src[(int64_t)r * stride + k];
@@ -132,7 +149,7 @@ __global__ void __launch_bounds__(P2P_NT) k_p2p_ar_sum(P2PWait w, int64_t seq, i
     }
 }
 
-static inline int p2p_blocks(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + P2P_NT - 1) / P2P_NT, 512)); }
+static inline int p2p_blocks(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + P2P_NT - 1) / P2P_NT, P2P_MAX_BLOCKS)); }
 static inline int64_t* flag_at(char* box, int which, int size, int r) {   // which: 0 forward / all-reduce, 1 reverse
     return reinterpret_cast<int64_t*>(box + ((size_t)which * size + r) * P2P_FLAG_STRIDE);
 }
@@ -168,10 +185,9 @@ int knp_p2p_halo_forward(knp_ctx* ctx, int plan, double* x) {
         a.flag[j] = flag_at(pb, 0, C.size, C.rank);
         w.flag[j] = flag_at(P.box, 0, C.size, P.peer_rank[j]);
     }
-    hipLaunchKernelGGL(k_p2p_pack, dim3(p2p_blocks(P.send_ptr[P.n_peers])), dim3(P2P_NT), 0, ctx->stream, a, P.d_send_idx, x, P.d_counter, seq);
     const double* src = reinterpret_cast<const double*>(P.box + P.hdr_bytes) + (int64_t)par * P.n_fwd;
-    hipLaunchKernelGGL(k_p2p_unpack_fwd, dim3(p2p_blocks(P.n_fwd)), dim3(P2P_NT), 0, ctx->stream, w, seq, P.n_fwd, P.d_recv_idx, src, x,
-                       C.timeout_ticks, C.h_err_dev, C.d_err);
+    hipLaunchKernelGGL(k_p2p_halo_fwd, dim3(p2p_blocks(std::max(P.send_ptr[P.n_peers], P.n_fwd))), dim3(P2P_NT), 0, ctx->stream, a, w,
+                       P.d_send_idx, P.n_fwd, P.d_recv_idx, src, x, P.d_counter, seq, C.timeout_ticks, C.h_err_dev, C.d_err);
     PCHK(hipGetLastError());
     return KNP_OK;
 }
@@ -184,19 +200,19 @@ int knp_p2p_halo_reverse(knp_ctx* ctx, int plan, double* x) {
     const int64_t seq = ++P.seq_rev;
     const int par = (int)(seq & 1);
     P2PSend a;
-    a.n = P.n_peers;
+    P2PWait w;
+    a.n = w.n = P.n_peers;
     for (int j = 0; j <= P.n_peers; ++j) a.ptr[j] = P.recv_ptr[j];     // roles swapped: I send my ghost copies
     for (int j = 0; j < P.n_peers; ++j) {
         char* pb = P.peer_box[P.peer_rank[j]];
         a.dst[j] = reinterpret_cast<double*>(pb + P.hdr_bytes) + P.remote_rev_off[2 * j + par];
         a.flag[j] = flag_at(pb, 1, C.size, C.rank);
+        w.flag[j] = flag_at(P.box, 1, C.size, P.peer_rank[j]);
     }
-    hipLaunchKernelGGL(k_p2p_pack, dim3(p2p_blocks(P.recv_ptr[P.n_peers])), dim3(P2P_NT), 0, ctx->stream, a, P.d_recv_idx, x, P.d_counter + 1, seq);
     const double* src = reinterpret_cast<const double*>(P.box + P.hdr_bytes) + 2 * P.n_fwd + (int64_t)par * P.n_rev;
-    for (int j = 0; j < P.n_peers; ++j)
-        hipLaunchKernelGGL(k_p2p_unpack_rev, dim3(p2p_blocks(P.send_ptr[j + 1] - P.send_ptr[j])), dim3(P2P_NT), 0, ctx->stream,
-                           flag_at(P.box, 1, C.size, P.peer_rank[j]), seq, P.send_ptr[j], P.send_ptr[j + 1], P.d_send_idx, src, x,
-                           C.timeout_ticks, C.h_err_dev, C.d_err);
+    hipLaunchKernelGGL(k_p2p_halo_rev, dim3(p2p_blocks(std::max<int64_t>(P.recv_ptr[P.n_peers], P.n_rev_dst))), dim3(P2P_NT), 0, ctx->stream, a, w,
+                       P.d_recv_idx, P.n_rev_dst, P.d_rev_dst, P.d_rev_ptr, P.d_rev_pos, src, x, P.d_counter + 1, seq, C.timeout_ticks,
+                       C.h_err_dev, C.d_err);
     PCHK(hipGetLastError());
     return KNP_OK;
 }
@@ -219,11 +235,10 @@ int knp_p2p_allreduce(knp_ctx* ctx, int plan, double* v, int n, double* mirror, 
         a.flag[r] = flag_at(pb, 0, C.size, C.rank);
         w.flag[r] = flag_at(P.box, 0, C.size, r);
     }
-    hipLaunchKernelGGL(k_p2p_ar_post, dim3(p2p_blocks((int64_t)n * C.size)), dim3(P2P_NT), 0, ctx->stream, a, n, v, P.d_counter, seq);
     const double* src = reinterpret_cast<const double*>(P.box + P.hdr_bytes) + (int64_t)par * C.size * P.n_fwd;
     const bool pub = seq_dev != nullptr && n <= P2P_NT;
-    hipLaunchKernelGGL(k_p2p_ar_sum, dim3(pub ? 1 : p2p_blocks(n)), dim3(P2P_NT), 0, ctx->stream, w, seq, n, P.n_fwd, src, v, mirror,
-                       pub ? seq_dev : nullptr, seq_val, C.timeout_ticks, C.h_err_dev, C.d_err);
+    hipLaunchKernelGGL(k_p2p_allreduce, dim3(pub ? 1 : p2p_blocks((int64_t)n * C.size)), dim3(P2P_NT), 0, ctx->stream, a, w, n, v, P.n_fwd, src,
+                       v, mirror, pub ? seq_dev : nullptr, seq_val, P.d_counter, seq, C.timeout_ticks, C.h_err_dev, C.d_err);
     PCHK(hipGetLastError());
     return KNP_OK;
 }
@@ -245,6 +260,9 @@ void knp_p2p_free(knp_ctx* ctx) {
         if (P.box) (void)hipFree(P.box);
         if (P.d_send_idx) (void)hipFree(P.d_send_idx);
         if (P.d_recv_idx) (void)hipFree(P.d_recv_idx);
+        if (P.d_rev_dst) (void)hipFree(P.d_rev_dst);
+        if (P.d_rev_ptr) (void)hipFree(P.d_rev_ptr);
+        if (P.d_rev_pos) (void)hipFree(P.d_rev_pos);
         if (P.d_counter) (void)hipFree(P.d_counter);
     }
     if (C.h_err) (void)hipHostFree(C.h_err);
@@ -342,6 +360,23 @@ int knp_p2p_plan_connect(knp_ctx* ctx, int32_t plan, const void* handles, int32_
         PCHK(hipMalloc((void**)&P.d_recv_idx, std::max<size_t>(P.n_fwd, 1) * sizeof(int32_t)));
         if (P.n_rev) PCHK(hipMemcpy(P.d_send_idx, send_idx, P.n_rev * sizeof(int32_t), hipMemcpyHostToDevice));
         if (P.n_fwd) PCHK(hipMemcpy(P.d_recv_idx, recv_idx, P.n_fwd * sizeof(int32_t), hipMemcpyHostToDevice));
+        {   // reverse halo: every owned entry with its mailbox positions in peer order (the send list is grouped by peer)
+            std::vector<int32_t> order(P.n_rev);
+            for (int64_t k = 0; k < P.n_rev; ++k) order[k] = (int32_t)k;
+            std::stable_sort(order.begin(), order.end(), [&](int32_t p, int32_t q) { return send_idx[p] < send_idx[q]; });
+            std::vector<int32_t> dst, ptr(1, 0);
+            for (int64_t k = 0; k < P.n_rev; ++k) {
+                if (k == 0 || send_idx[order[k]] != send_idx[order[k - 1]]) { dst.push_back(send_idx[order[k]]); ptr.push_back(ptr.back()); }
+                ptr.back() += 1;
+            }
+            P.n_rev_dst = (int64_t)dst.size();
+            PCHK(hipMalloc((void**)&P.d_rev_dst, std::max<size_t>(dst.size(), 1) * sizeof(int32_t)));
+            PCHK(hipMalloc((void**)&P.d_rev_ptr, ptr.size() * sizeof(int32_t)));
+            PCHK(hipMalloc((void**)&P.d_rev_pos, std::max<size_t>(order.size(), 1) * sizeof(int32_t)));
+            if (!dst.empty()) PCHK(hipMemcpy(P.d_rev_dst, dst.data(), dst.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            PCHK(hipMemcpy(P.d_rev_ptr, ptr.data(), ptr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            if (!order.empty()) PCHK(hipMemcpy(P.d_rev_pos, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
     } else {
         for (int r = 0; r < C.size; ++r) need[r] = (r != C.rank);
     }
