@@ -241,6 +241,11 @@ int knp_amg_set_level(knp_ctx* ctx, int32_t hier, int32_t level, int32_t n_rows,
                       const int32_t* R_rowptr, const int32_t* R_colind, const double* R_vals);
 /* distributed hierarchy: `distributed` != 0 -> the level operator has ghost columns (n_cols_halo local columns);
  * repl_n > 0 -> the next level is replicated on all ranks with repl_n unknowns */
+/* distributed levels: replace the prolongator by one that also has rows for the ghost entries (n_rows_P = local size).  The
+ * ghost part of the iterate then stays current through the coarse correction and the halo before the first post-smoothing
+ * step is skipped. */
+int knp_amg_set_level_prolongator(knp_ctx* ctx, int32_t hier, int32_t level, int32_t n_rows_P, const int32_t* P_rp,
+                                  const int32_t* P_ci, const double* P_v);
 int knp_amg_set_level_mode(knp_ctx* ctx, int32_t hier, int32_t level, int32_t distributed, int32_t repl_n);
 int knp_amg_set_coarse(knp_ctx* ctx, int32_t hier, int32_t n, const double* dense_inverse /* host [n*n] row-major */);
 /* level 0 == the library's own P (owned block): use its pair-major storage and node kernels instead of the uploaded

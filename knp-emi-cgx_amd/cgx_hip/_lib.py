@@ -86,6 +86,8 @@ SIGNATURES = {
     "knp_amg_set_level": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, i32p, i32p, f64p, f64p, C.c_double,
                                     C.c_int32, i32p, i32p, f64p, i32p, i32p, f64p]),
     "knp_amg_set_level_mode": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "knp_amg_set_level_prolongator": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                               C.POINTER(C.c_double)]),
     "knp_amg_set_coarse": (C.c_int, [vp, C.c_int32, C.c_int32, f64p]),
     "knp_amg_use_native_level0": (C.c_int, [vp, C.c_int32, C.c_int32]),
     "knp_amg_set_precision": (C.c_int, [vp, C.c_int32]),

@@ -104,7 +104,7 @@ class LevelHalo:
 
 
 class DistLevel:
-    __slots__ = ("A", "dinv", "lambda_max", "P", "R", "n_own", "n_loc", "halo", "gid_start", "ghost_gid",
+    __slots__ = ("A", "dinv", "lambda_max", "P", "P_loc", "R", "n_own", "n_loc", "halo", "gid_start", "ghost_gid",
                  "ghost_owner", "replicated", "n_coarse_own", "n_coarse_loc", "repl_n", "repl_offset")
 
 
@@ -139,7 +139,7 @@ def build_distributed_hierarchy(comm, P_loc: sp.csr_matrix, halo0: LevelHalo, ow
         L = DistLevel()
         L.A, L.dinv, L.lambda_max, L.n_own, L.n_loc, L.halo = A, dinv, lam, n_own, n_loc, halo
         L.gid_start, L.ghost_gid, L.ghost_owner = gid_start, ghost_gid, ghost_owner
-        L.P = L.R = None
+        L.P = L.R = L.P_loc = None
         L.replicated = False
         n_glob = int(comm.allreduce_sum(float((diag != 0.0).sum())))
         if len(levels) >= max_levels - 1:
@@ -195,11 +195,13 @@ def build_distributed_hierarchy(comm, P_loc: sp.csr_matrix, halo0: LevelHalo, ow
         n_next_glob = nagg_glob
         replicate = n_next_glob <= replicate_below
         # prolongator / restrictor in the next level's LOCAL column numbering
-        used_cols = np.unique(np.concatenate([Pm_own.indices, Ac_glob.indices]))
+        # (the prolongator rows of the ghost nodes are applied locally too, so their coarse columns must be local as well)
+        used_cols = np.unique(np.concatenate([Pm_own.indices, Pm_ghost.indices, Ac_glob.indices]))
         ghost_cols = used_cols[(used_cols < offs[rank]) | (used_cols >= offs[rank + 1])]
         if replicate:
             # columns stay global: the coarse vector is replicated
             L.P = Pm_own.tocsr()
+            L.P_loc = Pm_loc.tocsr()             # + rows of the ghost nodes: their iterate stays current without a halo
             L.R = Pm_own.T.tocsr()               # nagg_glob x n_own ; the result is all-reduced over ranks
             L.replicated = True
             L.n_coarse_own, L.n_coarse_loc = int(nagg), nagg_glob
@@ -219,6 +221,7 @@ def build_distributed_hierarchy(comm, P_loc: sp.csr_matrix, halo0: LevelHalo, ow
             M = M.tocoo()
             return sp.csr_matrix((M.data, (M.row, col_map[M.col])), shape=(n_rows, n_c_loc))
         L.P = relabel(Pm_own, n_own)                      # n_own x n_c_loc (needs ghost coarse values: forward halo)
+        L.P_loc = relabel(Pm_loc, n_loc)                  # + rows of the ghost nodes
         L.R = L.P.T.tocsr()                               # n_c_loc x n_own (ghost rows -> reverse halo to their owners)
         L.n_coarse_own, L.n_coarse_loc = int(nagg), n_c_loc
         levels.append(L)
@@ -329,6 +332,9 @@ def upload(lib, ctx, check, levels, tail, pre=1, post=1, cheby_degree=2, index=0
             check(lib.knp_amg_set_level(ctx, index, l, L.n_own, L.n_loc, ip(rp), ip(ci), fp(va), fp(dinv), float(L.lambda_max),
                                         0, None, None, None, None, None, None))
         check(lib.knp_amg_set_level_mode(ctx, index, l, 1, int(L.repl_n) if L.replicated else 0))
+        if L.P_loc is not None and L.n_loc > L.n_own:
+            Prp, Pci, Pv = arrs(L.P_loc)
+            check(lib.knp_amg_set_level_prolongator(ctx, index, l, L.n_loc, ip(Prp), ip(Pci), fp(Pv)))
     for k, lv in enumerate(tail_levels):
         l = len(levels) + k
         rp, ci, va = arrs(lv.A)

@@ -104,6 +104,7 @@ struct KnpAmgLevel {
     double* A_v = nullptr;
     float *A_vf = nullptr, *P_vf = nullptr, *R_vf = nullptr;   // fp32 copies (mixed-precision preconditioner storage)
     int p2p_halo = -1, p2p_repl = -1;   // native exchange plans of this level (-1: hook)
+    int P_rows = 0;                     // rows of the prolongator: n, or n_loc when it also prolongates the ghost entries
     double* inv_diag = nullptr;
     double lambda_max = 1.0;
     int32_t *P_rp = nullptr, *P_ci = nullptr;

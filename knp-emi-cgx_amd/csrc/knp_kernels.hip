@@ -1892,6 +1892,7 @@ int knp_amg_set_level(knp_ctx* ctx, int32_t hier, int32_t level, int32_t n_rows,
             KCHK(dev_upload_raw(ctx, &L.R_v, R_v, (size_t)nnzR));
         }
         L.P_lanes = pick_lanes((double)nnzP / n_rows);
+        L.P_rows = n_rows;
         L.R_lanes = pick_lanes((double)nnzR / n_coarse);
     }
     HIPCHK(hipMalloc((void**)&L.x, (size_t)n_loc * sizeof(double)));
@@ -1903,6 +1904,29 @@ int knp_amg_set_level(knp_ctx* ctx, int32_t hier, int32_t level, int32_t n_rows,
     HIPCHK(hipMemset(L.r2, 0, (size_t)n_loc * sizeof(double)));
     HIPCHK(hipMemset(L.x, 0, (size_t)n_loc * sizeof(double)));
     HIPCHK(hipMemset(L.d, 0, (size_t)n_loc * sizeof(double)));
+    return KNP_OK;
+}
+int knp_amg_set_level_prolongator(knp_ctx* ctx, int32_t hier, int32_t level, int32_t n_rows_P, const int32_t* P_rp, const int32_t* P_ci,
+                                  const double* P_v) {
+    CHECK_CTX(ctx);
+    if (hier < 0 || hier >= KNP_MAX_HIER || level < 0 || level >= ctx->hier[hier].levels) { ctx->err = "bad arguments"; return KNP_E_ARG; }
+    KnpAmgLevel& L = ctx->hier[hier].lv[level];
+    if (L.n_coarse <= 0 || !P_rp || !P_ci || !P_v || n_rows_P < L.n || n_rows_P > L.n_loc) { ctx->err = "prolongator rows must cover the owned entries and at most the local ones"; return KNP_E_ARG; }
+    const int64_t nnzP = P_rp[n_rows_P];
+    for (int64_t k = 0; k < nnzP; ++k)
+        if (P_ci[k] < 0 || P_ci[k] >= L.n_coarse) { ctx->err = "AMG prolongator column out of range"; return KNP_E_ARG; }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    dev_free(L.P_rp); dev_free(L.P_ci); dev_free(L.P_v); dev_free(L.P_vf);
+    KCHK(dev_upload_raw(ctx, &L.P_rp, P_rp, (size_t)n_rows_P + 1));
+    KCHK(dev_upload_raw(ctx, &L.P_ci, P_ci, (size_t)nnzP));
+    if (ctx->amg_fp32) {
+        std::vector<float> tp(P_v, P_v + nnzP);
+        KCHK(dev_upload(ctx, &L.P_vf, tp));
+    } else {
+        KCHK(dev_upload_raw(ctx, &L.P_v, P_v, (size_t)nnzP));
+    }
+    L.P_rows = n_rows_P;
+    L.P_lanes = pick_lanes((double)nnzP / std::max(n_rows_P, 1));
     return KNP_OK;
 }
 int knp_amg_set_level_mode(knp_ctx* ctx, int32_t hier, int32_t level, int32_t distributed, int32_t repl_n) {
@@ -1971,7 +1995,7 @@ static inline bool level_comm_on(const knp_ctx* ctx) { return ctx->level_comm !=
 // *cur (ignored when zero_guess); the sweep alternates between bufA and bufB and leaves *cur pointing at
 // the buffer that holds the result.
 static void amg_smooth(knp_ctx* ctx, KnpAmgHier& H, int l, const double* b, double** cur, double* bufA, double* bufB, bool zero_guess,
-                       bool first_done = false) {
+                       bool first_done = false, bool ghosts_current = false) {
     KnpAmgLevel& L = H.lv[l];
     const double lmax = 1.1 * L.lambda_max, lmin = 0.1 * L.lambda_max;  // smoothing interval [0.1, 1.1] * lambda_max
     const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
@@ -1982,8 +2006,10 @@ static void amg_smooth(knp_ctx* ctx, KnpAmgHier& H, int l, const double* b, doub
     auto other = [&](double* p) { return p == bufA ? bufB : bufA; };
     const bool native0 = (l == 0) && H.native0 > 0;
     const int hidx = (int)(&H - ctx->hier);
+    bool skip_halo = ghosts_current;   // only the first operator application of the sweep may rely on it
     auto step = [&](double* xin, double c1, double c2, double* out) {
-        if (L.dist && level_comm_on(ctx)) level_exchange(ctx, hidx, l, 0, xin);
+        if (L.dist && level_comm_on(ctx) && !skip_halo) level_exchange(ctx, hidx, l, 0, xin);
+        skip_halo = false;
         if (native0)
             launch_pnode<0>(st, H.native0 - 1, ctx->spmv_group > 0 ? ctx->spmv_group : 8, ctx->g.n_nodes_owned,
                             L.dist ? ctx->g.n_nodes : ctx->g.n_nodes_owned, ctx->d_pair_ptr,
@@ -2080,8 +2106,12 @@ static double* amg_vcycle(knp_ctx* ctx, KnpAmgHier& H, int l, const double* b, d
     double* xc = amg_vcycle(ctx, H, l + 1, C.b, nullptr, fuse_first);
     if (C.dist && level_comm_on(ctx) && L.repl_n == 0) level_exchange(ctx, hidx, l + 1, 0, xc);
     // x += P x_c (fused)
-    launch_spmv_mp<2>(st, L.P_lanes, L.n, L.P_rp, L.P_ci, L.P_v, L.P_vf, xc, nullptr, cur);
-    for (int sw = 0; sw < H.post; ++sw) amg_smooth(ctx, H, l, b, &cur, bufA, bufB, false);
+    // with prolongator rows for the ghost entries (distributed levels) the ghosts of `cur` stay current: they held the
+    // pre-smoothed iterate since the halo before the residual, and get the same correction as on their owner
+    const int p_rows = L.P_rows > 0 ? L.P_rows : L.n;
+    launch_spmv_mp<2>(st, L.P_lanes, p_rows, L.P_rp, L.P_ci, L.P_v, L.P_vf, xc, nullptr, cur);
+    const bool ghosts_current = L.dist && p_rows == L.n_loc && p_rows > L.n;
+    for (int sw = 0; sw < H.post; ++sw) amg_smooth(ctx, H, l, b, &cur, bufA, bufB, false, false, sw == 0 && ghosts_current);
     return cur;
 }
 
