@@ -82,6 +82,7 @@ class SolverKNPEMI:
     amg_coarse_size = 2500
     amg_replicate_below = 300000
     amg_fp32 = True        # mixed-precision preconditioner storage (operators fp32, vectors/Krylov fp64)
+    amg_setup = "gpu"      # where the hierarchy is built: "gpu" (torch sparse products, cgx_hip/amg_gpu.py) | "host" (SciPy)
 
     def __init__(self, problem: ProblemKNPEMI, solver_config: dict):
         self.problem = problem
@@ -113,7 +114,7 @@ class SolverKNPEMI:
             if "ksp_max_it" in ks: self.ksp_max_it = int(ks["ksp_max_it"])
             if "gmres_restart" in ks: self.gmres_restart = int(ks["gmres_restart"])
             if "strict" in ks: self.strict = bool(ks["strict"])
-            for k in ("amg_theta", "amg_cheby_degree", "amg_pre", "amg_post", "amg_coarse_size", "amg_replicate_below", "amg_fp32"):
+            for k in ("amg_theta", "amg_cheby_degree", "amg_pre", "amg_post", "amg_coarse_size", "amg_replicate_below", "amg_fp32", "amg_setup"):
                 if k in ks: setattr(self, k, type(getattr(self, k))(ks[k]))
         if self.ksp_type != "gmres":
             raise NotImplementedError(f"ksp_type '{self.ksp_type}': only 'gmres' is implemented natively.")
@@ -162,14 +163,19 @@ class SolverKNPEMI:
                 self.P_ = "device CSR (see Backend.precond_csr)"
                 return
             P = P[:, :be.n_dof_owned].tocsr()          # per-rank block (block-Jacobi across GPUs)
+            if str(self.amg_setup) == "gpu":
+                from . import amg_gpu
+                build = lambda M: amg_gpu.build_hierarchy(M, theta=self.amg_theta, coarse_size=self.amg_coarse_size, device=be.device)
+            else:
+                build = lambda M: amg.build_hierarchy(M, theta=self.amg_theta, coarse_size=self.amg_coarse_size)
             if self._pc_kind == _lib.PC_AMG:
-                self.hierarchy = amg.build_hierarchy(P, theta=self.amg_theta, coarse_size=self.amg_coarse_size)
+                self.hierarchy = build(P)
                 amg.upload(be.lib, be.ctx, be.check, self.hierarchy, self.amg_pre, self.amg_post, self.amg_cheby_degree, index=0)
                 be.check(be.lib.knp_amg_use_native_level0(be.ctx, 0, 1))   # level 0 is the library's own P
                 self.hierarchies = [self.hierarchy]
             else:
-                hk = amg.build_hierarchy(amg.restrict_to_fields(P, (0, 1, 2)), theta=self.amg_theta, coarse_size=self.amg_coarse_size)
-                hp = amg.build_hierarchy(amg.restrict_to_fields(P, (3,)), theta=self.amg_theta, coarse_size=self.amg_coarse_size)
+                hk = build(amg.restrict_to_fields(P, (0, 1, 2)))
+                hp = build(amg.restrict_to_fields(P, (3,)))
                 amg.upload(be.lib, be.ctx, be.check, hk, self.amg_pre, self.amg_post, self.amg_cheby_degree, index=0)
                 amg.upload(be.lib, be.ctx, be.check, hp, self.amg_pre, self.amg_post, self.amg_cheby_degree, index=1)
                 be.check(be.lib.knp_amg_use_native_level0(be.ctx, 0, 2))   # ion fields of P

@@ -280,3 +280,25 @@ def test_membrane_programs_compile_to_native_code_for_gfx950():
     bad = np.array([[9999, 0, 0, 0]], dtype=np.int32)
     log = C.create_string_buffer(4096)
     assert lib.knp_jit_compile_check(bad.ctypes.data_as(C.POINTER(C.c_int32)), 1, b"gfx950", log, 4096) != 0
+
+
+def test_device_amg_setup_reproduces_the_host_setup():
+    """cgx_hip/amg_gpu.py (torch sparse products; run here on CPU tensors) builds the hierarchy of cgx_hip/amg.py: same
+    aggregates and level sizes, operators equal to rounding."""
+    import numpy as np
+    import knpemi_oracle as K
+    from cgx_hip import amg, amg_gpu
+    o = K.make_cube(8, models=K.CI_MODELS())
+    P = o.assemble_P()
+    for fields in ((0, 1, 2), (3,), (0, 1, 2, 3)):
+        Pm = amg.restrict_to_fields(P, fields) if len(fields) < 4 else P
+        h0 = amg.build_hierarchy(Pm, theta=0.08, coarse_size=100)
+        h1 = amg_gpu.build_hierarchy(Pm, theta=0.08, coarse_size=100, device="cpu")
+        assert h0.describe()["rows"] == h1.describe()["rows"] and len(h0.levels) >= 2
+        for a, b in zip(h0.levels, h1.levels):
+            assert abs(a.A - b.A).max() <= 1e-12 * abs(a.A).max()
+            assert abs(a.lambda_max - b.lambda_max) <= 1e-10 * a.lambda_max
+            assert np.abs(a.dinv - b.dinv).max() <= 1e-12 * np.abs(a.dinv).max()
+            if a.P is not None:
+                assert abs(a.P - b.P).max() <= 1e-12 and abs(a.R - b.R).max() <= 1e-12
+        assert np.abs(h0.coarse_inv - h1.coarse_inv).max() <= 1e-8 * np.abs(h0.coarse_inv).max()

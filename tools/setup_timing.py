@@ -4,7 +4,7 @@ import conftest  # noqa
 import torch
 from parity_utils import ci_config, make_problem
 from cgx_hip.parallel import stacked_cubes_local_mesh
-from cgx_hip import amg, _lib
+from cgx_hip import amg, amg_gpu, _lib
 from CGx.KNPEMI.KNPEMIx_solver import SolverKNPEMI
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 96
 T = {}
@@ -18,7 +18,10 @@ t = time.perf_counter(); s.setup_solver(); tick("backend (graph build, upload)",
 be = s.backend
 t = time.perf_counter(); be.assemble_precond(); P = be.precond_csr(); tick("assemble P + fetch CSR", t)
 t = time.perf_counter(); Pk = amg.restrict_to_fields(P, (0, 1, 2)); Pp = amg.restrict_to_fields(P, (3,)); tick("field restriction", t)
-t = time.perf_counter(); hk = amg.build_hierarchy(Pk, theta=s.amg_theta, coarse_size=s.amg_coarse_size); tick("hierarchy ions", t)
-t = time.perf_counter(); hp = amg.build_hierarchy(Pp, theta=s.amg_theta, coarse_size=s.amg_coarse_size); tick("hierarchy potential", t)
+mode = sys.argv[2] if len(sys.argv) > 2 else "gpu"
+bh = (lambda M: amg_gpu.build_hierarchy(M, theta=s.amg_theta, coarse_size=s.amg_coarse_size, device=be.device)) if mode == "gpu" else (lambda M: amg.build_hierarchy(M, theta=s.amg_theta, coarse_size=s.amg_coarse_size))
+t = time.perf_counter(); hk = bh(Pk); tick(f"hierarchy ions ({mode})", t)
+t = time.perf_counter(); hp = bh(Pp); tick(f"hierarchy potential ({mode})", t)
+print(hk.describe(), hp.describe())
 t = time.perf_counter(); amg.upload(be.lib, be.ctx, be.check, hk, 1, 1, 1, index=0); amg.upload(be.lib, be.ctx, be.check, hp, 1, 1, 1, index=1); tick("upload", t)
 print("n_dof", be.n_dof_owned, "total", sum(T.values()))
