@@ -92,13 +92,18 @@ __global__ void __launch_bounds__(NT) k_cell_means(int n_c, int nv1, const int32
     if (c >= n_c) return;
     const int s = side[c];
     const double inv = 1.0 / nv1;
+    double m[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const double* k = s ? f.ke[j] : f.ki[j];
         double acc = 0.0;
         for (int a = 0; a < nv1; ++a) acc += k[cells[(size_t)c * nv1 + a]];
-        cbar[(size_t)4 * c + j] = acc * inv;     // 32-B record per cell: one gather per contribution in K1
+        m[j] = acc * inv;
     }
+    // 32-B record per cell, written whole (two 16-B stores): one gather per contribution in K1
+    double2* out = reinterpret_cast<double2*>(cbar + (size_t)4 * c);
+    out[0] = make_double2(m[0], m[1]);
+    out[1] = make_double2(m[2], 0.0);
 }
 
 // ------------------------------------------------------------------------------------------
