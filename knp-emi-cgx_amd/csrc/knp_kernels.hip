@@ -967,8 +967,31 @@ __global__ void __launch_bounds__(NT) k_dense_matvec(int n, const VT* __restrict
     const int row = (blockIdx.x * NT + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     double s = 0.0;
-    if (row < n)
-        for (int k = lane; k < n; k += 64) s += (double)M[(size_t)row * n + k] * x[k];
+    if (row < n) {
+        const VT* __restrict__ m = M + (size_t)row * n;
+        if (sizeof(VT) == 8 && (n & 1) == 0) {
+            // 16-B loads (the row start is 16-B aligned for even n), two independent accumulators
+            const double2* m2 = reinterpret_cast<const double2*>(m);
+            const double2* x2 = reinterpret_cast<const double2*>(x);
+            const int n2 = n >> 1;
+            double s0 = 0.0, s1 = 0.0;
+            int k = lane;
+            for (; k + 64 < n2; k += 128) {
+                const double2 a = m2[k], b = m2[k + 64];
+                const double2 xa = x2[k], xb = x2[k + 64];
+                s0 += a.x * xa.x + a.y * xa.y;
+                s1 += b.x * xb.x + b.y * xb.y;
+            }
+            if (k < n2) {
+                const double2 a = m2[k];
+                const double2 xa = x2[k];
+                s0 += a.x * xa.x + a.y * xa.y;
+            }
+            s = s0 + s1;
+        } else {
+            for (int k = lane; k < n; k += 64) s += (double)m[k] * x[k];
+        }
+    }
     s = wave_sum(s);
     if (lane == 0 && row < n) y[row] = s;
 }
