@@ -99,7 +99,17 @@ def main():
     problem.solver_config["view_ksp"] = False
     for kv in args.set:
         k, v = kv.split("=", 1)
-        problem.solver_config["ksp_settings"][k] = (v.lower() == "true") if v.lower() in ("true", "false") else (float(v) if "." in v or "e" in v.lower() else int(v))
+        if v.lower() in ("true", "false"):
+            val = v.lower() == "true"
+        else:
+            try:
+                val = int(v)
+            except ValueError:
+                try:
+                    val = float(v)
+                except ValueError:
+                    val = v
+        problem.solver_config["ksp_settings"][k] = val
     solver = SolverKNPEMI(problem, solver_config=problem.solver_config)
 
     # ---- run the reference loop, but split into warmup and timed parts -------------------------
