@@ -163,11 +163,20 @@ class SolverKNPEMI:
                 self.P_ = "device CSR (see Backend.precond_csr)"
                 return
             P = P[:, :be.n_dof_owned].tocsr()          # per-rank block (block-Jacobi across GPUs)
+            host_build = lambda M: amg.build_hierarchy(M, theta=self.amg_theta, coarse_size=self.amg_coarse_size)
             if str(self.amg_setup) == "gpu":
                 from . import amg_gpu
-                build = lambda M: amg_gpu.build_hierarchy(M, theta=self.amg_theta, coarse_size=self.amg_coarse_size, device=be.device)
+
+                def build(M):
+                    # the setup is host logic either way (the V-cycle always runs in the library): if torch's sparse
+                    # products are not usable on this installation, build the same hierarchy with SciPy
+                    try:
+                        return amg_gpu.build_hierarchy(M, theta=self.amg_theta, coarse_size=self.amg_coarse_size, device=be.device)
+                    except (RuntimeError, NotImplementedError) as exc:
+                        self.print(f"device-side AMG setup unavailable ({type(exc).__name__}: {exc}); using the host setup")
+                        return host_build(M)
             else:
-                build = lambda M: amg.build_hierarchy(M, theta=self.amg_theta, coarse_size=self.amg_coarse_size)
+                build = host_build
             if self._pc_kind == _lib.PC_AMG:
                 self.hierarchy = build(P)
                 amg.upload(be.lib, be.ctx, be.check, self.hierarchy, self.amg_pre, self.amg_post, self.amg_cheby_degree, index=0)
