@@ -77,17 +77,42 @@ class LocalMesh:
     defl: dict | None = None
 
 
-def vertex_partition(coords, size):
-    """Coordinate slabs along the longest axis with equal vertex counts (deterministic)."""
+def vertex_partition(coords, size, method=None):
+    """Owner rank of every vertex.  ``rcb`` (default): recursive coordinate bisection -- the vertex set is cut at the
+    (size-proportional) median along its longest axis, recursively, which gives compact subdomains with small
+    interfaces (the geometric stand-in for the reference's METIS/ParMETIS partition of the dual graph; neither is
+    available here).  ``slab``: 1-D slabs along the longest axis.  Deterministic; ``KNP_PARTITION`` overrides."""
+    import os
+    n = coords.shape[0]
     if size == 1:
-        return np.zeros(coords.shape[0], dtype=np.int32)
-    ext = coords.max(axis=0) - coords.min(axis=0)
-    ax = int(np.argmax(ext))
-    order = np.lexsort(tuple(coords[:, k] for k in range(coords.shape[1])) + (coords[:, ax],))
-    owner = np.empty(coords.shape[0], dtype=np.int32)
-    bounds = np.linspace(0, coords.shape[0], size + 1).astype(np.int64)
-    for r in range(size):
-        owner[order[bounds[r]:bounds[r + 1]]] = r
+        return np.zeros(n, dtype=np.int32)
+    method = method or os.environ.get("KNP_PARTITION", "rcb")
+    dim = coords.shape[1]
+
+    def sorted_along(idx, ax):
+        # ties broken by the remaining coordinates (lexicographic), then by index: deterministic
+        keys = tuple(coords[idx, k] for k in range(dim)) + (coords[idx, ax],)
+        return idx[np.lexsort(keys)]
+    owner = np.empty(n, dtype=np.int32)
+    if method == "slab":
+        ext = coords.max(axis=0) - coords.min(axis=0)
+        order = sorted_along(np.arange(n), int(np.argmax(ext)))
+        bounds = np.linspace(0, n, size + 1).astype(np.int64)
+        for r in range(size):
+            owner[order[bounds[r]:bounds[r + 1]]] = r
+        return owner
+    stack = [(np.arange(n), 0, size)]
+    while stack:
+        idx, r0, parts = stack.pop()
+        if parts == 1:
+            owner[idx] = r0
+            continue
+        ext = coords[idx].max(axis=0) - coords[idx].min(axis=0)
+        order = sorted_along(idx, int(np.argmax(ext)))
+        left = parts // 2
+        cut = int(round(len(order) * left / parts))
+        stack.append((order[:cut], r0, left))
+        stack.append((order[cut:], r0 + left, parts - left))
     return owner
 
 
