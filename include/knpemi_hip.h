@@ -155,9 +155,9 @@ int knp_set_comm(knp_ctx* ctx, knp_halo_fn halo, knp_allreduce_fn allreduce, voi
 int knp_set_level_comm(knp_ctx* ctx, knp_level_comm_fn fn);
 
 /* ---- native peer-to-peer exchange (multi-GPU, optional; replaces the hooks above once attached) ----
- * Ghost values and reduction partials are written by a pack kernel straight into the neighbour's mailbox (uncached device
- * memory mapped over hipIpc: xGMI stores between GPUs) and announced by a sequence flag; the consuming kernel waits on the
- * flag.  No host round trip, no library call per exchange.  The rendezvous (who are my peers, their IPC handles, where
+ * One kernel per exchange: it writes this rank's ghost values / reduction partials straight into the neighbours' mailboxes
+ * (uncached device memory mapped over hipIpc: xGMI stores between GPUs), announces them with a sequence flag, waits for the
+ * neighbours' flags (bounded) and consumes its own mailbox.  No host round trip, no library call per exchange.  The rendezvous (who are my peers, their IPC handles, where
  * my data lands in their mailbox) is done by the caller with whatever it has (torch.distributed, MPI):
  *   knp_p2p_init            once per ctx
  *   knp_p2p_plan_create     allocates this rank's mailbox of one plan, returns its 64-byte IPC handle
@@ -179,9 +179,10 @@ int knp_p2p_plan_create(knp_ctx* ctx, int32_t kind, int64_t n_fwd /* halo: ghost
 int knp_p2p_plan_connect(knp_ctx* ctx, int32_t plan, const void* handles /* host [size*64], one per rank */,
                          int32_t n_peers, const int32_t* peer_rank /* host, ascending */,
                          const int64_t* send_ptr /* host [n_peers+1] */, const int32_t* send_idx /* host: owned entries each peer needs */,
-                         const int64_t* remote_fwd_off /* host [n_peers]: where my values start in the peer's ghost list */,
+                         const int64_t* remote_fwd_off /* host [2*n_peers]: element offset of my values in the peer's mailbox data
+                                                          area, for sequence parity 0 and 1 (the mailboxes are double buffered) */,
                          const int64_t* recv_ptr /* host [n_peers+1] */, const int32_t* recv_idx /* host: my ghost entries per peer */,
-                         const int64_t* remote_rev_off /* host [n_peers]: where my ghost copies start in the peer's send list */);
+                         const int64_t* remote_rev_off /* host [2*n_peers]: the same for the reverse (ghost -> owner) direction */);
 int knp_p2p_attach(knp_ctx* ctx, int32_t what, int32_t hier, int32_t level, int32_t plan /* -1 detaches */);
 int knp_p2p_test_halo(knp_ctx* ctx, int32_t plan, double* x /* device */, int32_t reverse);
 int knp_p2p_test_allreduce(knp_ctx* ctx, int32_t plan, double* v /* device */, int32_t n);
@@ -239,13 +240,13 @@ int knp_amg_set_level(knp_ctx* ctx, int32_t hier, int32_t level, int32_t n_rows,
                       int32_t n_coarse,
                       const int32_t* P_rowptr, const int32_t* P_colind, const double* P_vals,
                       const int32_t* R_rowptr, const int32_t* R_colind, const double* R_vals);
-/* distributed hierarchy: `distributed` != 0 -> the level operator has ghost columns (n_cols_halo local columns);
- * repl_n > 0 -> the next level is replicated on all ranks with repl_n unknowns */
 /* distributed levels: replace the prolongator by one that also has rows for the ghost entries (n_rows_P = local size).  The
  * ghost part of the iterate then stays current through the coarse correction and the halo before the first post-smoothing
  * step is skipped. */
 int knp_amg_set_level_prolongator(knp_ctx* ctx, int32_t hier, int32_t level, int32_t n_rows_P, const int32_t* P_rp,
                                   const int32_t* P_ci, const double* P_v);
+/* distributed hierarchy: `distributed` != 0 -> the level operator has ghost columns (n_cols_halo local columns);
+ * repl_n > 0 -> the next level is replicated on all ranks with repl_n unknowns */
 int knp_amg_set_level_mode(knp_ctx* ctx, int32_t hier, int32_t level, int32_t distributed, int32_t repl_n);
 int knp_amg_set_coarse(knp_ctx* ctx, int32_t hier, int32_t n, const double* dense_inverse /* host [n*n] row-major */);
 /* level 0 == the library's own P (owned block): use its pair-major storage and node kernels instead of the uploaded
