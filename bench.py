@@ -128,8 +128,10 @@ def main():
                 if isinstance(model, HodgkinHuxley):
                     model.update_t_mod()
                     model.update_gating_variables()
-        be.assemble_matrix()
         be.assemble_rhs()
+        if i > 1:
+            be.gmres_prepare()          # ||B b|| on the side stream while the matrix is assembled (as SolverKNPEMI.assemble does)
+        be.assemble_matrix()
         if i == 1:
             solver.create_and_set_nullspace()
         its, rnorm, reason = be.gmres(solver._rtol, 1e-50, solver.ksp_max_it, solver.gmres_restart)

@@ -472,6 +472,10 @@ class Backend:
     def spmv(self, x: torch.Tensor, y: torch.Tensor):
         self.check(self.lib.knp_spmv(self.ctx, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr())))
 
+    def gmres_prepare(self):
+        """Start ||B b|| of the next solve on the library's side stream (b must be final); overlaps the matrix assembly."""
+        self.check(self.lib.knp_gmres_prepare(self.ctx, C.c_void_p(self.b.data_ptr())))
+
     def gmres(self, rtol, atol=1e-50, max_it=5000, restart=30):
         its = C.c_int32()
         rn = C.c_double()

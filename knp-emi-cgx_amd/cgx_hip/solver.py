@@ -82,6 +82,7 @@ class SolverKNPEMI:
     amg_coarse_size = 2500
     amg_replicate_below = 300000
     amg_fp32 = True        # mixed-precision preconditioner storage (operators fp32, vectors/Krylov fp64)
+    _b_is_final = False
     amg_setup = "gpu"      # where the hierarchy is built: "gpu" (torch sparse products, cgx_hip/amg_gpu.py) | "host" (SciPy)
 
     def __init__(self, problem: ProblemKNPEMI, solver_config: dict):
@@ -137,7 +138,8 @@ class SolverKNPEMI:
         self.print("Assembling linear system ...")
         be = self.backend
         p = self.problem
-        be.assemble_matrix()
+        # right-hand side first: its preconditioned norm (the first thing the solve needs) then runs on a side stream
+        # while the matrix is assembled (the reference assembles A then b, :114-116; the two are independent)
         be.assemble_rhs()
         if p.MMS_test:
             # extra terms of L for the manufactured solution (KNPEMIx_problem.py:616-651): host integrals of the
@@ -148,6 +150,9 @@ class SolverKNPEMI:
             extra = p._mms_asm.rhs_vector(be.node_i, be.node_e, be.n_dof_local)
             be.b += torch.as_tensor(extra, dtype=torch.float64, device=be.device)
         be.apply_dirichlet_rhs()
+        if self._b_is_final:
+            be.gmres_prepare()
+        be.assemble_matrix()
 
     # ---- reference :118-135
     def assemble_preconditioner(self):
@@ -323,6 +328,7 @@ class SolverKNPEMI:
                 self.ode_time.append(self.comm.allreduce_max(time.perf_counter() - tic))
 
             tic = time.perf_counter()
+            self._b_is_final = i > 1          # step 1: the null-space projection still modifies b after the assembly
             self.assemble()
             if i > 1 and self.reassemble_P and (i % self.reassemble_N == 0) and self.use_P_mat and self._pc_kind in (_lib.PC_AMG, _lib.PC_AMG_BT):
                 self.reassemble_preconditioner()

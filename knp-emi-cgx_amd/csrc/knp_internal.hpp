@@ -231,6 +231,10 @@ struct knp_ctx {
     int p2p_red = -1;    // all-reduce of the reduction slots
     bool hook_allreduce() const { return allreduce && p2p_red < 0; }
     int comm_rc = 0;     // first failure of a level exchange inside a preconditioner application
+    // side stream for ||B b|| of the next solve (knp_gmres_prepare)
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    const double* prep_b = nullptr;
     // profiling
     int prof_on = 0;
     struct ProfRec { hipEvent_t a, b; int cls; };

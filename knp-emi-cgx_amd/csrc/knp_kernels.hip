@@ -60,6 +60,7 @@ struct FieldPtrs {
     const double* aux[KNP_MAX_AUX];
 };
 
+static void side_discard(knp_ctx* ctx);
 static inline int nblocks(int64_t n, int per = NT) { return (int)std::max<int64_t>(1, (n + per - 1) / per); }
 
 // ------------------------------------------------------------------------------------------
@@ -1306,6 +1307,7 @@ int knp_create(knp_ctx** out, const knp_mesh_desc* mesh) {
 int knp_destroy(knp_ctx* ctx) {
     if (!ctx) return KNP_OK;
     (void)hipDeviceSynchronize();
+    if (ctx->stream2) { (void)hipEventDestroy(ctx->ev_fork); (void)hipEventDestroy(ctx->ev_join); (void)hipStreamDestroy(ctx->stream2); }
     knp_p2p_free(ctx);
     knp_jit_release(ctx);
     for (auto& r : ctx->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -1522,6 +1524,7 @@ const char* knp_jit_status(knp_ctx* ctx) {
 
 int knp_set_dirichlet(knp_ctx* ctx, int32_t n, const int32_t* dofs) {
     CHECK_CTX(ctx);
+    side_discard(ctx);
     if (n < 0 || (n > 0 && !dofs)) { ctx->err = "bad Dirichlet arguments"; return KNP_E_ARG; }
     for (int i = 0; i < n; ++i)
         if (dofs[i] < 0 || dofs[i] >= ctx->n_dof_owned) { ctx->err = "Dirichlet dof out of range (owned dofs only)"; return KNP_E_ARG; }
@@ -1616,6 +1619,7 @@ int knp_assemble_matrix(knp_ctx* ctx, const knp_fields* fields) {
 
 int knp_assemble_precond(knp_ctx* ctx, const knp_fields* fields) {
     CHECK_CTX(ctx);
+    side_discard(ctx);
     KCHK(check_fields(ctx, fields, false));
     const KnpHostGraph& g = ctx->g;
     const DevParams P = make_params(ctx);
@@ -1642,6 +1646,7 @@ int knp_assemble_precond(knp_ctx* ctx, const knp_fields* fields) {
 
 int knp_assemble_rhs(knp_ctx* ctx, const knp_fields* fields, double* b) {
     CHECK_CTX(ctx);
+    side_discard(ctx);
     KCHK(check_fields(ctx, fields, true));
     if (!b) { ctx->err = "null b"; return KNP_E_ARG; }
     const KnpHostGraph& g = ctx->g;
@@ -1772,6 +1777,7 @@ static int64_t global_phi_count(knp_ctx* ctx, int* rc) {
 
 int knp_set_nullspace(knp_ctx* ctx, int32_t on) {
     CHECK_CTX(ctx);
+    side_discard(ctx);
     ctx->ns_on = on ? 1 : 0;
     return KNP_OK;
 }
@@ -1792,6 +1798,7 @@ static int project_ns(knp_ctx* ctx, double* v) {
 }
 int knp_project_nullspace(knp_ctx* ctx, double* v) {
     CHECK_CTX(ctx);
+    side_discard(ctx);
     if (!v) return KNP_E_ARG;
     return project_ns(ctx, v);
 }
@@ -1851,6 +1858,7 @@ int knp_spmv(knp_ctx* ctx, const double* x, double* y) {
 
 int knp_nullspace_test(knp_ctx* ctx, double* out_norm) {
     CHECK_CTX(ctx);
+    side_discard(ctx);
     if (!out_norm) return KNP_E_ARG;
     if (!ctx->have_A) { ctx->err = "matrix not assembled"; return KNP_E_STATE; }
     KCHK(ensure_work(ctx, 0));
@@ -1881,6 +1889,7 @@ static void free_hier(KnpAmgHier& H) {
 }
 int knp_amg_reset(knp_ctx* ctx, int32_t hier, int32_t n_levels, int32_t pre, int32_t post, int32_t cheby) {
     CHECK_CTX(ctx);
+    side_discard(ctx);
     if (hier < 0 || hier >= KNP_MAX_HIER || n_levels < 1 || n_levels > KNP_MAX_AMG_LEVELS || pre < 0 || post < 0 || cheby < 1) { ctx->err = "bad AMG parameters"; return KNP_E_ARG; }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     KnpAmgHier& H = ctx->hier[hier];
@@ -2170,6 +2179,7 @@ static int check_hier(knp_ctx* ctx, int h) {
 
 int knp_pc_setup(knp_ctx* ctx, int32_t kind) {
     CHECK_CTX(ctx);
+    side_discard(ctx);
     if (kind != KNP_PC_NONE && kind != KNP_PC_VBJACOBI && kind != KNP_PC_AMG && kind != KNP_PC_AMG_BT) { ctx->err = "unknown pc kind"; return KNP_E_ARG; }
     if (kind == KNP_PC_AMG) KCHK(check_hier(ctx, 0));
     if (kind == KNP_PC_AMG_BT) {
@@ -2276,6 +2286,7 @@ static int pc_apply_proj(knp_ctx* ctx, const double* r, double* z, int64_t cnt) 
 
 int knp_set_deflation(knp_ctx* ctx, int32_t n_modes, const int32_t* node_mode, const double* einv) {
     CHECK_CTX(ctx);
+    side_discard(ctx);
     if (n_modes < 0 || n_modes > DEFL_MAX || (n_modes > 0 && (!node_mode || !einv))) { ctx->err = "bad deflation arguments (at most 32 modes)"; return KNP_E_ARG; }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->defl_m = 0;
@@ -2292,6 +2303,7 @@ int knp_set_deflation(knp_ctx* ctx, int32_t n_modes, const int32_t* node_mode, c
 
 int knp_pc_apply(knp_ctx* ctx, const double* r, double* z) {
     CHECK_CTX(ctx);
+    side_discard(ctx);
     if (!r || !z) return KNP_E_ARG;
     int rc;
     const int64_t cnt = ctx->ns_on ? global_phi_count(ctx, &rc) : 0;
@@ -2299,6 +2311,45 @@ int knp_pc_apply(knp_ctx* ctx, const double* r, double* z) {
 }
 
 // ---- GMRES(restart), left preconditioning, classical Gram-Schmidt (KSPGMRES semantics) ------
+// ---- ||B b|| of the next solve on a side stream ------------------------------------------------------------------------
+// The first preconditioner application of a solve only needs the right-hand side, not the matrix: started right after the
+// right-hand side is assembled it overlaps the matrix assembly of the same timestep (separate HIP streams; the V-cycle's
+// coarse levels are launch-latency bound, the assembly is bandwidth bound).
+static void side_discard(knp_ctx* ctx) {   // any call that could touch what the side stream uses joins it first
+    if (ctx->prep_b) {
+        (void)hipEventSynchronize(ctx->ev_join);
+        ctx->prep_b = nullptr;
+    }
+}
+
+int knp_gmres_prepare(knp_ctx* ctx, const double* b) {
+    CHECK_CTX(ctx);
+    if (!b) return KNP_E_ARG;
+    side_discard(ctx);
+    // single-GPU contexts only (the exchanges of a distributed preconditioner are ordered on the main stream), and only
+    // once the Krylov workspace exists (second solve onwards)
+    if (ctx->halo || ctx->allreduce || ctx->level_comm || ctx->p2p || ctx->gm_restart <= 0 || (ctx->prof_on & ~1)) return KNP_OK;
+    if (!ctx->stream2) {
+        HIPCHK(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
+    int rc = KNP_OK;
+    const int64_t cnt = ctx->ns_on ? global_phi_count(ctx, &rc) : 0;
+    KCHK(rc);
+    HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
+    HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+    hipStream_t main_stream = ctx->stream;
+    ctx->stream = ctx->stream2;
+    rc = pc_apply_proj(ctx, b, ctx->d_w, cnt);
+    if (rc == KNP_OK) rc = dot_to_slot(ctx, ctx->d_w, ctx->d_w, 60);
+    ctx->stream = main_stream;
+    KCHK(rc);
+    HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
+    ctx->prep_b = b;
+    return KNP_OK;
+}
+
 int knp_gmres_solve(knp_ctx* ctx, const double* b, double* x, double rtol, double atol, int32_t max_it, int32_t restart,
                     int32_t* its, double* rnorm, int32_t* reason) {
     CHECK_CTX(ctx);
@@ -2318,9 +2369,18 @@ int knp_gmres_solve(knp_ctx* ctx, const double* b, double* x, double rtol, doubl
     auto Hx = [&](int i, int j) -> double& { return H[(size_t)i + (size_t)j * (m + 1)]; };
 
     // ||M b|| for the relative tolerance (non-zero initial guess, preconditioned norm)
-    KCHK(pc_apply_proj(ctx, b, ctx->d_w, cnt));
-    KCHK(dot_to_slot(ctx, ctx->d_w, ctx->d_w, 60));
-    KCHK(read_slots(ctx, 60, 1, ctx->seq_counter));
+    if (ctx->prep_b == b && restart == ctx->gm_restart) {   // already computed on the side stream (knp_gmres_prepare)
+        HIPCHK(hipEventSynchronize(ctx->ev_join));
+        ctx->prep_b = nullptr;
+        if (!ctx->h_red_dev) {
+            HIPCHK(hipMemcpy(ctx->h_red + 60, ctx->d_red + 60, sizeof(double), hipMemcpyDeviceToHost));
+        }
+    } else {
+        side_discard(ctx);
+        KCHK(pc_apply_proj(ctx, b, ctx->d_w, cnt));
+        KCHK(dot_to_slot(ctx, ctx->d_w, ctx->d_w, 60));
+        KCHK(read_slots(ctx, 60, 1, ctx->seq_counter));
+    }
     const double bnorm = std::sqrt(ctx->h_red[60]);
     if (!std::isfinite(bnorm)) { *its = 0; *rnorm = bnorm; *reason = KNP_DIVERGED_NANORINF; return KNP_OK; }
     const double ttol = std::max(rtol * bnorm, atol);
@@ -2470,6 +2530,7 @@ int knp_hh_update(knp_ctx* ctx, const double* phi_m, double* n, double* m, doubl
 }
 int knp_l2_norms(knp_ctx* ctx, const double* phi_i, const double* phi_e, double* out) {
     CHECK_CTX(ctx);
+    side_discard(ctx);
     if (!phi_i || !phi_e || !out) return KNP_E_ARG;
     const KnpHostGraph& g = ctx->g;
     const int nb = std::min(RED_BLOCKS, nblocks(g.n_c_owned));
