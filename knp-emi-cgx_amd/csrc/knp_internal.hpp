@@ -195,6 +195,7 @@ struct knp_ctx {
     // null space
     int ns_on = 0;
     int spmv_group = 8;   // lanes per node of the node-structured SpMV (0 = generic CSR kernel)
+    int pc_group = 8;     // lanes per node of the level-0 preconditioner kernels (k_pnode, k_phi_rhs)
     // GMRES workspace
     int gm_restart = 0;
     double* d_V = nullptr;       // [(restart+1)*n_dof_local]

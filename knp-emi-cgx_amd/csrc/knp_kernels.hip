@@ -1297,6 +1297,10 @@ int knp_create(knp_ctx** out, const knp_mesh_desc* mesh) {
         const char* e = getenv("KNP_SPMV");
         if (e && !strcmp(e, "csr")) ctx->spmv_group = 0;   // generic CSR kernel (k_spmv<L,*,1>)
         else if (e && atoi(e) > 0) ctx->spmv_group = atoi(e);
+        // the level-0 preconditioner kernels move half the bytes per node pair (fp32 P, no cross block): fewer lanes per node
+        ctx->pc_group = std::max(4, (ctx->spmv_group > 0 ? ctx->spmv_group : 16) / 2);
+        const char* ep = getenv("KNP_PC_GROUP");
+        if (ep && atoi(ep) > 0) ctx->pc_group = atoi(ep);
     }
     // free the big host arrays that are no longer needed (pattern kept for export)
     std::vector<int32_t>().swap(g.contrib_cell);
@@ -2061,7 +2065,7 @@ static void amg_smooth(knp_ctx* ctx, KnpAmgHier& H, int l, const double* b, doub
         if (L.dist && level_comm_on(ctx) && !skip_halo) level_exchange(ctx, hidx, l, 0, xin);
         skip_halo = false;
         if (native0)
-            launch_pnode<0>(st, H.native0 - 1, ctx->spmv_group > 0 ? ctx->spmv_group : 8, ctx->g.n_nodes_owned,
+            launch_pnode<0>(st, H.native0 - 1, ctx->pc_group, ctx->g.n_nodes_owned,
                             L.dist ? ctx->g.n_nodes : ctx->g.n_nodes_owned, ctx->d_pair_ptr,
                             ctx->d_pair_col, ctx->d_p_vals, ctx->d_p_vals_f, L.inv_diag, b, xin, c1, c2, L.d, out);
         else
@@ -2129,7 +2133,7 @@ static double* amg_vcycle(knp_ctx* ctx, KnpAmgHier& H, int l, const double* b, d
     const int hidx = (int)(&H - ctx->hier);
     if (L.dist && level_comm_on(ctx)) level_exchange(ctx, hidx, l, 0, cur);
     if (l == 0 && H.native0 > 0)
-        launch_pnode<1>(st, H.native0 - 1, ctx->spmv_group > 0 ? ctx->spmv_group : 8, ctx->g.n_nodes_owned,
+        launch_pnode<1>(st, H.native0 - 1, ctx->pc_group, ctx->g.n_nodes_owned,
                         L.dist ? ctx->g.n_nodes : ctx->g.n_nodes_owned, ctx->d_pair_ptr,
                         ctx->d_pair_col, ctx->d_p_vals, ctx->d_p_vals_f, L.inv_diag, b, cur, 0.0, 0.0, L.d, L.r);
     else
@@ -2241,7 +2245,7 @@ static int pc_apply_proj(knp_ctx* ctx, const double* r, double* z, int64_t cnt) 
             case KNP_PC_AMG_BT: {
                 // z_k = V_k r_k ; t_phi = r_phi - A_{phi k} z_k ; z_phi = V_phi t_phi + cc * t_phi
                 if (!ctx->have_A || !ctx->have_cc) { ctx->err = "block-triangular preconditioner needs an assembled matrix"; return KNP_E_STATE; }
-                const int G = ctx->spmv_group > 0 ? ctx->spmv_group : 8;
+                const int G = ctx->pc_group;
                 double* out = amg_vcycle(ctx, ctx->hier[0], 0, r, z);
                 if (out != z) HIPCHK(hipMemcpyAsync(z, out, (size_t)ctx->n_dof_owned * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
                 KCHK(halo_update(ctx, z));   // the mass-matrix row may reach ghost ion unknowns
