@@ -624,11 +624,13 @@ static void launch_restrict_first_t(hipStream_t st, int lanes, int n_rows, const
     }
 }
 
-static int pick_lanes(double avg_nnz_per_row) {
+static int pick_lanes(double avg_nnz_per_row, int role = 0) {   // role 0 level operator, 1 prolongator, 2 restrictor
     // lanes per row of the generic CSR kernels (AMG level operators, transfer operators).  About 6 entries per lane:
     // measured on MI355X, halving the lane counts of the first version (3 per lane) gave +4 % on square512
-    static const double scale = getenv("KNP_LANE_SCALE") ? atof(getenv("KNP_LANE_SCALE")) : 1.0;   // tuning knob
-    avg_nnz_per_row *= scale;
+    static const double scale = getenv("KNP_LANE_SCALE") ? atof(getenv("KNP_LANE_SCALE")) : 1.0;   // tuning knobs
+    static const double scale_p = getenv("KNP_LANE_SCALE_P") ? atof(getenv("KNP_LANE_SCALE_P")) : 1.0;
+    static const double scale_r = getenv("KNP_LANE_SCALE_R") ? atof(getenv("KNP_LANE_SCALE_R")) : 1.0;
+    avg_nnz_per_row *= scale * (role == 1 ? scale_p : role == 2 ? scale_r : 1.0);
     if (avg_nnz_per_row <= 6.0) return 2;
     if (avg_nnz_per_row <= 12.0) return 4;
     if (avg_nnz_per_row <= 28.0) return 8;
@@ -1949,9 +1951,9 @@ int knp_amg_set_level(knp_ctx* ctx, int32_t hier, int32_t level, int32_t n_rows,
             KCHK(dev_upload_raw(ctx, &L.P_v, P_v, (size_t)nnzP));
             KCHK(dev_upload_raw(ctx, &L.R_v, R_v, (size_t)nnzR));
         }
-        L.P_lanes = pick_lanes((double)nnzP / n_rows);
+        L.P_lanes = pick_lanes((double)nnzP / n_rows, 1);
         L.P_rows = n_rows;
-        L.R_lanes = pick_lanes((double)nnzR / n_coarse);
+        L.R_lanes = pick_lanes((double)nnzR / n_coarse, 2);
     }
     HIPCHK(hipMalloc((void**)&L.x, (size_t)n_loc * sizeof(double)));
     HIPCHK(hipMalloc((void**)&L.b, (size_t)n_loc * sizeof(double)));
@@ -1984,7 +1986,7 @@ int knp_amg_set_level_prolongator(knp_ctx* ctx, int32_t hier, int32_t level, int
         KCHK(dev_upload_raw(ctx, &L.P_v, P_v, (size_t)nnzP));
     }
     L.P_rows = n_rows_P;
-    L.P_lanes = pick_lanes((double)nnzP / std::max(n_rows_P, 1));
+    L.P_lanes = pick_lanes((double)nnzP / std::max(n_rows_P, 1), 1);
     return KNP_OK;
 }
 int knp_amg_set_level_mode(knp_ctx* ctx, int32_t hier, int32_t level, int32_t distributed, int32_t repl_n) {
