@@ -105,6 +105,8 @@ struct KnpAmgLevel {
     float *A_vf = nullptr, *P_vf = nullptr, *R_vf = nullptr;   // fp32 copies (mixed-precision preconditioner storage)
     int p2p_halo = -1, p2p_repl = -1;   // native exchange plans of this level (-1: hook)
     int P_rows = 0;                     // rows of the prolongator: n, or n_loc when it also prolongates the ghost entries
+    int P_n_act = 0;                    // > 0: compact list of the non-empty prolongator rows (field-restricted hierarchies)
+    int32_t *P_act_rows = nullptr, *P_act_rp = nullptr;
     double* inv_diag = nullptr;
     double lambda_max = 1.0;
     int32_t *P_rp = nullptr, *P_ci = nullptr;

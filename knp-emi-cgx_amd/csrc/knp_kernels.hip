@@ -586,6 +586,37 @@ static void launch_spmv_mp(hipStream_t st, int lanes, int n_rows, const int32_t*
     else launch_spmv_t<MODE, 0, double>(st, lanes, n_rows, rp, ci, v, x, b, y);
 }
 
+// Prolongation with a compact row list: a hierarchy restricted to one field class has a prolongator whose rows for the
+// other fields are empty (3/4 of the rows for the potential hierarchy); only the non-empty rows are visited.
+//   y[rows[i]] += sum_k v[k] x[ci[k]],  k in [rp[i], rp[i+1])
+template <int L, typename VT>
+__global__ void __launch_bounds__(NT)
+k_prolong_rows(int n_act, const int32_t* __restrict__ rows, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
+               const VT* __restrict__ v, const double* __restrict__ x, double* __restrict__ y) {
+    const int gid = blockIdx.x * NT + threadIdx.x;
+    const int i = gid / L;
+    const int lane = threadIdx.x & (L - 1);
+    double s = 0.0;
+    if (i < n_act) {
+        const int e = rp[i + 1];
+        for (int k = rp[i] + lane; k < e; k += L) s += (double)v[k] * x[ci[k]];
+    }
+#pragma unroll
+    for (int o = L >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, L);
+    if (lane == 0 && i < n_act) y[rows[i]] += s;
+}
+template <typename VT>
+static void launch_prolong_rows_t(hipStream_t st, int lanes, int n_act, const int32_t* rows, const int32_t* rp, const int32_t* ci,
+                                  const VT* v, const double* x, double* y) {
+    if (n_act <= 0) return;
+    switch (lanes) {
+        case 2: hipLaunchKernelGGL((k_prolong_rows<2, VT>), dim3(nblocks((int64_t)n_act * 2)), dim3(NT), 0, st, n_act, rows, rp, ci, v, x, y); break;
+        case 4: hipLaunchKernelGGL((k_prolong_rows<4, VT>), dim3(nblocks((int64_t)n_act * 4)), dim3(NT), 0, st, n_act, rows, rp, ci, v, x, y); break;
+        case 8: hipLaunchKernelGGL((k_prolong_rows<8, VT>), dim3(nblocks((int64_t)n_act * 8)), dim3(NT), 0, st, n_act, rows, rp, ci, v, x, y); break;
+        default: hipLaunchKernelGGL((k_prolong_rows<16, VT>), dim3(nblocks((int64_t)n_act * 16)), dim3(NT), 0, st, n_act, rows, rp, ci, v, x, y); break;
+    }
+}
+
 // Restriction fused with the first Chebyshev step of the coarse level (zero initial guess):
 //   b_c = R r ;  d_c = x_c = (1/theta_c) D_c^-1 b_c       -- one launch instead of two on every level of every cycle
 template <int L, typename VT>
@@ -1345,7 +1376,7 @@ int knp_destroy(knp_ctx* ctx) {
             KnpAmgLevel& L = H.lv[l];
             dev_free(L.A_rp); dev_free(L.A_ci); dev_free(L.A_v); dev_free(L.inv_diag);
             dev_free(L.P_rp); dev_free(L.P_ci); dev_free(L.P_v); dev_free(L.R_rp); dev_free(L.R_ci); dev_free(L.R_v);
-            dev_free(L.A_vf); dev_free(L.P_vf); dev_free(L.R_vf);
+            dev_free(L.A_vf); dev_free(L.P_vf); dev_free(L.R_vf); dev_free(L.P_act_rows); dev_free(L.P_act_rp); L.P_n_act = 0;
             dev_free(L.x); dev_free(L.b); dev_free(L.r); dev_free(L.d); dev_free(L.r2);
         }
         dev_free(H.cinv); dev_free(H.cinv_f);
@@ -1890,7 +1921,7 @@ static void free_hier(KnpAmgHier& H) {
         KnpAmgLevel& L = H.lv[l];
         dev_free(L.A_rp); dev_free(L.A_ci); dev_free(L.A_v); dev_free(L.inv_diag);
         dev_free(L.P_rp); dev_free(L.P_ci); dev_free(L.P_v); dev_free(L.R_rp); dev_free(L.R_ci); dev_free(L.R_v);
-        dev_free(L.A_vf); dev_free(L.P_vf); dev_free(L.R_vf);
+        dev_free(L.A_vf); dev_free(L.P_vf); dev_free(L.R_vf); dev_free(L.P_act_rows); dev_free(L.P_act_rp); L.P_n_act = 0;
         dev_free(L.x); dev_free(L.b); dev_free(L.r); dev_free(L.d); dev_free(L.r2);
         L.n = L.n_coarse = 0;
     }
@@ -1907,6 +1938,22 @@ int knp_amg_reset(knp_ctx* ctx, int32_t hier, int32_t n_levels, int32_t pre, int
     H.levels = n_levels; H.pre = pre; H.post = post; H.cheby = cheby;
     return KNP_OK;
 }
+// compact row list of a prolongator when a good part of its rows is empty
+static int build_prolong_rows(knp_ctx* ctx, KnpAmgLevel& L, int n_rows_P, const int32_t* P_rp) {
+    dev_free(L.P_act_rows); dev_free(L.P_act_rp);
+    L.P_n_act = 0;
+    std::vector<int32_t> rows, rp(1, 0);
+    for (int r = 0; r < n_rows_P; ++r)
+        if (P_rp[r + 1] > P_rp[r]) { rows.push_back(r); rp.push_back(P_rp[r + 1]); }
+    if ((double)rows.size() > 0.8 * n_rows_P || rows.empty()) return KNP_OK;   // dense enough: the plain kernel is fine
+    // non-empty rows are contiguous in the value array only if no empty row lies between entries -- they are: CSR rows are
+    // consecutive, empty rows contribute nothing, so rp of the compact list is the running end pointer
+    KCHK(dev_upload(ctx, &L.P_act_rows, rows));
+    KCHK(dev_upload(ctx, &L.P_act_rp, rp));
+    L.P_n_act = (int)rows.size();
+    return KNP_OK;
+}
+
 int knp_amg_set_level(knp_ctx* ctx, int32_t hier, int32_t level, int32_t n_rows, int32_t n_cols_halo, const int32_t* A_rp,
                       const int32_t* A_ci, const double* A_v, const double* inv_diag, double lambda_max, int32_t n_coarse,
                       const int32_t* P_rp, const int32_t* P_ci, const double* P_v, const int32_t* R_rp, const int32_t* R_ci,
@@ -1953,6 +2000,8 @@ int knp_amg_set_level(knp_ctx* ctx, int32_t hier, int32_t level, int32_t n_rows,
         }
         L.P_lanes = pick_lanes((double)nnzP / n_rows, 1);
         L.P_rows = n_rows;
+        KCHK(build_prolong_rows(ctx, L, n_rows, P_rp));
+        if (L.P_n_act > 0) L.P_lanes = pick_lanes((double)nnzP / L.P_n_act, 1);
         L.R_lanes = pick_lanes((double)nnzR / n_coarse, 2);
     }
     HIPCHK(hipMalloc((void**)&L.x, (size_t)n_loc * sizeof(double)));
@@ -1987,6 +2036,8 @@ int knp_amg_set_level_prolongator(knp_ctx* ctx, int32_t hier, int32_t level, int
     }
     L.P_rows = n_rows_P;
     L.P_lanes = pick_lanes((double)nnzP / std::max(n_rows_P, 1), 1);
+    KCHK(build_prolong_rows(ctx, L, n_rows_P, P_rp));
+    if (L.P_n_act > 0) L.P_lanes = pick_lanes((double)nnzP / L.P_n_act, 1);
     return KNP_OK;
 }
 int knp_amg_set_level_mode(knp_ctx* ctx, int32_t hier, int32_t level, int32_t distributed, int32_t repl_n) {
@@ -2169,7 +2220,12 @@ static double* amg_vcycle(knp_ctx* ctx, KnpAmgHier& H, int l, const double* b, d
     // with prolongator rows for the ghost entries (distributed levels) the ghosts of `cur` stay current: they held the
     // pre-smoothed iterate since the halo before the residual, and get the same correction as on their owner
     const int p_rows = L.P_rows > 0 ? L.P_rows : L.n;
-    launch_spmv_mp<2>(st, L.P_lanes, p_rows, L.P_rp, L.P_ci, L.P_v, L.P_vf, xc, nullptr, cur);
+    if (L.P_n_act > 0) {
+        if (L.P_vf) launch_prolong_rows_t<float>(st, L.P_lanes, L.P_n_act, L.P_act_rows, L.P_act_rp, L.P_ci, L.P_vf, xc, cur);
+        else launch_prolong_rows_t<double>(st, L.P_lanes, L.P_n_act, L.P_act_rows, L.P_act_rp, L.P_ci, L.P_v, xc, cur);
+    } else {
+        launch_spmv_mp<2>(st, L.P_lanes, p_rows, L.P_rp, L.P_ci, L.P_v, L.P_vf, xc, nullptr, cur);
+    }
     const bool ghosts_current = L.dist && p_rows == L.n_loc && p_rows > L.n;
     for (int sw = 0; sw < H.post; ++sw) amg_smooth(ctx, H, l, b, &cur, bufA, bufB, false, false, sw == 0 && ghosts_current);
     return cur;
