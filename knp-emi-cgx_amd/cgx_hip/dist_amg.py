@@ -27,6 +27,64 @@ import torch.distributed as dist
 from . import amg
 
 
+class _Accel:
+    """The heavy local steps of the distributed setup on the device (cgx_hip/amg_gpu.py: sparse products through
+    torch, segmented reductions), with the SciPy/NumPy versions as fallback (CPU tensors, gloo tests).  The glue --
+    object exchanges between ranks, relabelling -- stays on the host either way."""
+
+    def __init__(self, device):
+        self.dev = torch.device(device) if device is not None else torch.device("cpu")
+        self.gpu = self.dev.type == "cuda"
+        if self.gpu:
+            from . import amg_gpu
+            self.G = amg_gpu
+
+    def strength_and_aggregate(self, Aoo, theta, active_idx, seed):
+        """S (host csr pattern of the owned-owned block) and the aggregates of its active sub-graph"""
+        if not self.gpu:
+            S = amg.strength_graph(Aoo, theta)
+            if active_idx.size:
+                agg, nagg = amg.aggregate(S[active_idx][:, active_idx].tocsr(), seed=seed)
+            else:
+                agg, nagg = np.zeros(0, np.int64), 0
+            return S, agg, nagg
+        G = self.G
+        n = Aoo.shape[0]
+        Ad = G._from_scipy(Aoo, self.dev)
+        skey = G._strength(Ad, theta)
+        crow, col = G._pattern_csr(skey, n)
+        S = sp.csr_matrix((np.ones(int(col.numel())), col.cpu().numpy().astype(np.int32), crow.cpu().numpy().astype(np.int32)), shape=(n, n))
+        if not active_idx.size:
+            return S, np.zeros(0, np.int64), 0
+        n_act = int(active_idx.size)
+        if n_act == n:
+            agg, nagg = G._aggregate(crow, col, n, seed, 2)
+        else:
+            active = torch.zeros(n, dtype=torch.bool, device=self.dev)
+            active[torch.as_tensor(active_idx, device=self.dev)] = True
+            newid = torch.cumsum(active.to(torch.int64), 0) - 1
+            rr = torch.div(skey, n, rounding_mode="floor")
+            cc = skey - rr * n
+            both = active[rr] & active[cc]
+            crow_s, col_s = G._pattern_csr(newid[rr[both]] * n_act + newid[cc[both]], n_act)
+            agg, nagg = G._aggregate(crow_s, col_s, n_act, seed, 2)
+        return S, agg.cpu().numpy(), int(nagg)
+
+    def matmul(self, A, B):
+        """sparse product A @ B (host csr in, host csr out)"""
+        if not self.gpu or A.nnz == 0 or B.nnz == 0:
+            return (A @ B).tocsr()
+        G = self.G
+        return G._spgemm(G._from_scipy(A, self.dev), G._from_scipy(B, self.dev)).scipy()
+
+    def matvec_fn(self, A):
+        """y = A @ x for a device vector x -> NumPy result"""
+        if not self.gpu:
+            return lambda x: A @ x.cpu().numpy()
+        At = self.G._from_scipy(A, self.dev).torch()
+        return lambda x: (At @ x.unsqueeze(1)).squeeze(1).cpu().numpy()
+
+
 class LevelHalo:
     """Forward / reverse halo of one level.  Local vector layout: [owned (n_own) | ghost (n_ghost)].
     One packed send buffer and ONE ``all_to_all_single`` per exchange (three torch calls per halo)."""
@@ -122,6 +180,7 @@ def build_distributed_hierarchy(comm, P_loc: sp.csr_matrix, halo0: LevelHalo, ow
     ``levels`` are DistLevel objects (distributed part) and ``serial_tail`` is an ``amg.Hierarchy`` for the
     replicated coarse problem (identical on every rank)."""
     levels = []
+    X = _Accel(device)
     A = sp.csr_matrix(P_loc, dtype=np.float64)
     A.sort_indices()
     halo = halo0
@@ -135,7 +194,7 @@ def build_distributed_hierarchy(comm, P_loc: sp.csr_matrix, halo0: LevelHalo, ow
         diag = Aoo.diagonal()
         dinv = np.where(diag != 0.0, 1.0 / np.where(diag != 0.0, diag, 1.0), 0.0)
         # lambda_max of D^-1 A over the distributed operator: power iteration with halos
-        lam = _dist_lambda_max(comm, A, dinv, halo)
+        lam = _dist_lambda_max(comm, A, dinv, halo, matvec=X.matvec_fn(A))
         L = DistLevel()
         L.A, L.dinv, L.lambda_max, L.n_own, L.n_loc, L.halo = A, dinv, lam, n_own, n_loc, halo
         L.gid_start, L.ghost_gid, L.ghost_owner = gid_start, ghost_gid, ghost_owner
@@ -146,10 +205,9 @@ def build_distributed_hierarchy(comm, P_loc: sp.csr_matrix, halo0: LevelHalo, ow
             levels.append(L)
             return levels, None
         # ---- aggregation on the owned-owned block (aggregates never cross ranks)
-        S = amg.strength_graph(Aoo, theta * 0.25 ** len(levels))
         active = diag != 0.0
         ia = np.nonzero(active)[0]
-        agg_a, nagg = amg.aggregate(S[ia][:, ia].tocsr(), seed=len(levels)) if ia.size else (np.zeros(0, np.int64), 0)
+        S, agg_a, nagg = X.strength_and_aggregate(Aoo, theta * 0.25 ** len(levels), ia, len(levels))
         counts = comm.all_gather_object(int(nagg))
         offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
         nagg_glob = int(offs[-1])
@@ -169,14 +227,14 @@ def build_distributed_hierarchy(comm, P_loc: sp.csr_matrix, halo0: LevelHalo, ow
         AF = (AF + sp.hstack([sp.diags(lump), sp.csr_matrix((n_own, n_loc - n_own))])).tocsr()
         dF = AF[:, :n_own].diagonal()
         dFinv = np.where(dF != 0.0, 1.0 / np.where(dF != 0.0, dF, 1.0), 0.0)
-        lamF = _dist_lambda_max(comm, AF, dFinv, halo, iters=15)
+        lamF = _dist_lambda_max(comm, AF, dFinv, halo, iters=15, matvec=X.matvec_fn(AF))
         omega = 4.0 / (3.0 * lamF)
-        Pm_own = (T[:n_own] - sp.diags(omega * dFinv) @ (AF @ T)).tocsr()          # n_own x nagg_glob
+        Pm_own = (T[:n_own] - sp.diags(omega * dFinv) @ X.matmul(AF, T)).tocsr()    # n_own x nagg_glob
         # rows of the smoothed prolongator for ghost nodes (owned by neighbours)
         Pm_ghost = _exchange_rows(comm, halo, Pm_own, n_loc - n_own, nagg_glob)
         Pm_loc = sp.vstack([Pm_own, Pm_ghost]).tocsr()
         # Galerkin product: local contribution, rows/cols in global aggregate ids; off-rank rows go to their owners
-        C = (Pm_own.T @ (A @ Pm_loc)).tocoo()
+        C = X.matmul(Pm_own.T.tocsr(), X.matmul(A, Pm_loc)).tocoo()
         row_owner = np.searchsorted(offs, C.row, side="right") - 1
         mine = row_owner == rank
         out = {}
@@ -245,7 +303,7 @@ def _ghost_strength(A, n_own, theta, diag_own, halo):
     return sp.csr_matrix((np.ones(int(keep.sum())), (B.row[keep], B.col[keep])), shape=(n_own, n_loc - n_own))
 
 
-def _dist_lambda_max(comm, A, dinv, halo, iters=20, seed=1):
+def _dist_lambda_max(comm, A, dinv, halo, iters=20, seed=1, matvec=None):
     n_own, n_loc = A.shape
     rng = np.random.default_rng(seed + comm.rank)
     x = torch.zeros(n_loc, dtype=torch.float64, device=halo.device)
@@ -256,7 +314,7 @@ def _dist_lambda_max(comm, A, dinv, halo, iters=20, seed=1):
     for _ in range(iters):
         x[:n_own] = torch.as_tensor(xo, device=halo.device)
         halo.forward(x)
-        y = dinv * (A @ x.cpu().numpy())
+        y = dinv * (matvec(x) if matvec is not None else A @ x.cpu().numpy())
         lam = np.sqrt(comm.allreduce_sum(float(y @ y)))
         if lam == 0.0:
             return 1.0
