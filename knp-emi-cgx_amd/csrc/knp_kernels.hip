@@ -2394,7 +2394,8 @@ int knp_gmres_prepare(knp_ctx* ctx, const double* b) {
     side_discard(ctx);
     // single-GPU contexts only (the exchanges of a distributed preconditioner are ordered on the main stream), and only
     // once the Krylov workspace exists (second solve onwards)
-    if (ctx->halo || ctx->allreduce || ctx->level_comm || ctx->p2p || ctx->gm_restart <= 0 || (ctx->prof_on & ~1)) return KNP_OK;
+    static const bool off = getenv("KNP_NO_PREPARE") != nullptr;
+    if (off || ctx->halo || ctx->allreduce || ctx->level_comm || ctx->p2p || ctx->gm_restart <= 0 || (ctx->prof_on & ~1)) return KNP_OK;
     if (!ctx->stream2) {
         HIPCHK(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));

@@ -391,3 +391,30 @@ def test_pin_ecs_potential(monkeypatch):
     assert np.ptp(shift) <= 1e-6 * np.abs(o.phi[0]).max()          # potentials differ by one constant only
     for j in range(3):
         assert np.allclose(p.wh[1][j].numpy()[ve], o.k[1][j][ve], rtol=1e-7)
+
+
+def _run_in_subprocess(env_extra):
+    """three CI steps in a fresh interpreter (the library reads its environment switches once per process)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = ("import sys; sys.path[:0]=['tests','oracle','knp-emi-cgx_amd']; import conftest, json, numpy as np\n"
+            "from parity_utils import ci_config, run_native\n"
+            "s = run_native(ci_config(N=24, steps=3, rtol=1e-10, pc='btcc', kind='square'))\n"
+            "x = s.backend.x.cpu().numpy()\n"
+            "print('RESULT' + json.dumps({'its': list(s.iterations), 'sum': float(x.sum()), 'l1': float(np.abs(x).sum())}))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=300)
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")]
+    assert line, out.stdout[-2000:] + out.stderr[-2000:]
+    return json.loads(line[0][6:])
+
+
+def test_side_stream_prenorm_changes_nothing():
+    """knp_gmres_prepare computes ||B b|| on a side stream while the matrix is assembled: same iteration counts and the
+    same solution, bit for bit, as the in-line computation (KNP_NO_PREPARE=1)."""
+    a = _run_in_subprocess({})
+    b = _run_in_subprocess({"KNP_NO_PREPARE": "1"})
+    assert a["its"] == b["its"]
+    assert a["sum"] == b["sum"] and a["l1"] == b["l1"]
