@@ -9,93 +9,117 @@ Workload (synthetic, deterministic, no RNG): BASELINE.json configs[1] -- the 512
 inner square [0.25,0.75]^2 as one cell, 3 ions, the CI physics of the reference's test YAML
 (HH + ATP pump + neuronal cotransporters), mesh scaled to micrometres, dt 25 us, rtol 1e-9.  With N GPUs the
 domain is N such unit squares stacked along y (one per rank, weak scaling, fixed work per GPU) with
-ghost-layer halo exchange and Krylov all-reduces over RCCL.  ``--workload cubeM`` selects the 3D analogue.
+ghost-layer halo exchange and Krylov all-reduces over xGMI.  ``--workload cubeM`` selects the 3D analogue,
+``--workload tissue...`` the tissue surrogates.
 
-Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the byte model of `roofline`).
+``python bench.py --gpus N`` started WITHOUT a launcher (no WORLD_SIZE in the environment) starts its N ranks
+itself as child processes before anything touches the GPU; under ``python -m torch.distributed.run`` it is one rank.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the byte model of `roofline`).  The timed region
+is ``--steps`` timesteps between barriers; when that is shorter than ~0.5 s the bracket is repeated (the simulation
+simply continues) and the MEDIAN repetition is reported -- every repetition is listed under ``timing``.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import re
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for _p in (os.path.join(ROOT, "knp-emi-cgx_amd"), os.path.join(ROOT, "tests")):
-    if _p not in sys.path:
-        sys.path.insert(0, _p)
+PKG = os.path.join(ROOT, "knp-emi-cgx_amd")
+if PKG not in sys.path:
+    sys.path.insert(0, PKG)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MIN_TIMED_S = 0.5         # repeat the K-step bracket until this much has been timed
+MAX_REPS = 40
+PARITY_TOL = 1e-6         # north_star: potentials match the reference solve to rtol 1e-6
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", type=str, default="square512",
-                    help="square<N> | cube<N> (per-GPU mesh, weak scaling) | tissue<dim>d_<N>_<m> (lattice of m^dim cells, one tag "
-                         "per cell: the tissue surrogate of SURVEY 8d; the global mesh is partitioned over the ranks)")
+                    help="square<N> | cube<N> (per-GPU mesh, weak scaling) | tissue<dim>d_<N>_<m>[_g<gap>|_w<width>] (lattice of m^dim "
+                         "cells, one tag per cell: the tissue surrogate of SURVEY 8d; the global mesh is partitioned over the ranks)")
     ap.add_argument("--pc", type=str, default="auto", help="auto (hypre-form AMG in 2D, btcc in 3D) | hypre | btcc | vbjacobi | none")
     ap.add_argument("--rtol", type=float, default=1e-9)
     ap.add_argument("--models", type=str, default="ci", help="ci (HH+ATP+cotransporters) | passive")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
-    ap.add_argument("--profile-all", action="store_true", help="time every kernel class with HIP events (adds overhead)")
+    ap.add_argument("--large", type=str, default="cube136", help="out-of-cache workload of the roofline_large block ('' or 'none' disables)")
+    ap.add_argument("--large-steps", type=int, default=4)
+    ap.add_argument("--no-repeat", action="store_true", help="time the K steps once, whatever their duration")
+    ap.add_argument("--profile-all", action="store_true", help="time every kernel class with HIP events in the MAIN run (adds overhead)")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
                     help="override a ksp_settings entry (e.g. --set amg_cheby_degree=2); tuning runs only")
     return ap.parse_args()
 
 
-def main():
-    args = parse()
-    import torch
-    import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = os.environ.get("KNP_DIST_BACKEND", "nccl")      # "gloo": rehearsal with several ranks on one GPU
-        dev_index = local_rank % max(torch.cuda.device_count(), 1)
-        torch.cuda.set_device(dev_index)
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    else:
-        torch.cuda.set_device(0)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+# --------------------------------------------------------------------------------------------------------------
+# launcher: N ranks as child processes (no GPU call, no torch import in this parent)
+# --------------------------------------------------------------------------------------------------------------
+def launch_ranks(n):
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"bench.py: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                for q in alive:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return rc
 
-    import re
-    from parity_utils import ci_config, make_problem, tissue_config
-    from cgx_hip import _lib
+
+# --------------------------------------------------------------------------------------------------------------
+def build_case(workload, args, world, rank, steps_total):
+    from cgx_hip.configs import ci_config, make_problem, tissue_config
     from cgx_hip.parallel import stacked_cubes_local_mesh, stacked_squares_local_mesh
     from CGx.KNPEMI.KNPEMIx_solver import SolverKNPEMI
-
-    total_steps = args.warmup + args.steps
-    mt = re.fullmatch(r"tissue(\d)d_(\d+)_(\d+)", args.workload)
-    m = re.fullmatch(r"(square|cube)(\d+)", args.workload)
-    assert m or mt, "workload must be square<N>, cube<N> or tissue<dim>d_<N>_<m>"
+    mt = re.fullmatch(r"tissue(\d)d_(\d+)_(\d+)(?:_g(\d+))?(?:_w(\d+))?", workload)
+    m = re.fullmatch(r"(square|cube)(\d+)", workload)
+    assert m or mt, "workload must be square<N>, cube<N> or tissue<dim>d_<N>_<m>[_g<gap>|_w<width>]"
+    pc = args.pc
     if mt:
         tdim, N, ncell = int(mt.group(1)), int(mt.group(2)), int(mt.group(3))
         kind = "square" if tdim == 2 else "cube"
-        if args.pc == "auto":
-            args.pc = "hypre" if tdim == 2 else "btcc"
-        cfg = tissue_config(tdim, N, ncell, steps=total_steps, rtol=args.rtol, pc=args.pc, stimulus=(args.models == "ci"))
+        if pc == "auto":
+            pc = "hypre" if tdim == 2 else "btcc"
+        cfg = tissue_config(tdim, N, ncell, steps=steps_total, rtol=args.rtol, pc=pc, stimulus=(args.models == "ci"),
+                            gap=int(mt.group(4)) if mt.group(4) else None, width=int(mt.group(5)) if mt.group(5) else None)
         problem = make_problem(cfg, models=args.models)          # the problem partitions the global mesh itself
-        what = f"tissue surrogate: unit {kind} {N}^{tdim} with {ncell}^{tdim} cells (one tag each), over {world} GPU(s)"
+        what = f"tissue surrogate {workload}: unit {kind} {N}^{tdim} with {ncell}^{tdim} cells (one tag each), over {world} GPU(s)"
     else:
         kind, N = m.group(1), int(m.group(2))
-        if args.pc == "auto":
-            args.pc = "hypre" if kind == "square" else "btcc"
+        if pc == "auto":
+            pc = "hypre" if kind == "square" else "btcc"
         gen = stacked_squares_local_mesh if kind == "square" else stacked_cubes_local_mesh
         lm = gen(N, world, rank, scale=1e-6)
-        cfg = ci_config(N=N, steps=total_steps, rtol=args.rtol, pc=args.pc, kind=kind)
+        cfg = ci_config(N=N, steps=steps_total, rtol=args.rtol, pc=pc, kind=kind)
         problem = make_problem(cfg, models=args.models, local_mesh=lm)
-        what = f"{world} x unit {kind} {N}^{2 if kind == 'square' else 3} (BASELINE configs[{1 if kind == 'square' else 2}])"
+        what = f"{world} x unit {kind} {N}^{2 if kind == 'square' else 3} (BASELINE configs[{1 if kind == 'square' else 2}])" if N in (512, 64) \
+            else f"{world} x unit {kind} {N}^{2 if kind == 'square' else 3}"
     problem.solver_config["view_ksp"] = False
     for kv in args.set:
         k, v = kv.split("=", 1)
@@ -111,157 +135,310 @@ def main():
                     val = v
         problem.solver_config["ksp_settings"][k] = val
     solver = SolverKNPEMI(problem, solver_config=problem.solver_config)
+    return {"problem": problem, "solver": solver, "kind": kind, "N": N, "pc": pc, "what": what, "tissue": bool(mt)}
 
-    # ---- run the reference loop, but split into warmup and timed parts -------------------------
-    from cgx_hip.ionic_models import HodgkinHuxley
-    solver.setup_solver()
-    be = solver.backend
-    if solver._pc_kind in (_lib.PC_AMG, _lib.PC_AMG_BT):
-        problem.setup_preconditioner(solver.use_block_Jacobi)
-        solver.assemble_preconditioner()
-    be.pc_setup(solver._pc_kind)
 
-    def one_step(i):
-        problem.t.value += float(problem.dt.value)
-        if problem.gating_variables:
-            for model in problem.ionic_models:
-                if isinstance(model, HodgkinHuxley):
+class Stepper:
+    """The reference loop body (KNPEMIx_solver.py:365-468), one call per timestep."""
+
+    def __init__(self, case):
+        from cgx_hip import _lib
+        from cgx_hip.ionic_models import HodgkinHuxley
+        self.HH = HodgkinHuxley
+        self.solver, self.problem = case["solver"], case["problem"]
+        s = self.solver
+        s.setup_solver()
+        self.be = s.backend
+        if s._pc_kind in (_lib.PC_AMG, _lib.PC_AMG_BT):
+            self.problem.setup_preconditioner(s.use_block_Jacobi)
+            s.assemble_preconditioner()
+        self.be.pc_setup(s._pc_kind)
+        self.i = 0
+
+    def step(self):
+        self.i += 1
+        p, s, be = self.problem, self.solver, self.be
+        p.t.value += float(p.dt.value)
+        if p.gating_variables:
+            for model in p.ionic_models:
+                if isinstance(model, self.HH):
                     model.update_t_mod()
                     model.update_gating_variables()
         be.assemble_rhs()
-        if i > 1:
+        if self.i > 1:
             be.gmres_prepare()          # ||B b|| on the side stream while the matrix is assembled (as SolverKNPEMI.assemble does)
         be.assemble_matrix()
-        if i == 1:
-            solver.create_and_set_nullspace()
-        its, rnorm, reason = be.gmres(solver._rtol, 1e-50, solver.ksp_max_it, solver.gmres_restart)
+        if self.i == 1:
+            s.create_and_set_nullspace()
+        its, rnorm, reason = be.gmres(s._rtol, 1e-50, s.ksp_max_it, s.gmres_restart)
         be.unpack()
         return its, reason
+
+
+def spmv_bytes(be):
+    """Bytes one SpMV on A must move: the node-structured kernel reads the matrix values (8 B/nnz)
+    but only a 4-B neighbour index per node pair instead of a 4-B column index per entry.  Returns (node kernel, CSR)."""
+    n_own, n_loc = be.n_dof_owned, be.n_dof_local
+    b_csr = 12.0 * be.nnz + 4.0 * (n_own + 1) + 8.0 * n_own + 8.0 * n_loc          # SURVEY 8(d) CSR figure
+    b_node = 8.0 * be.nnz + 4.0 * be.n_pairs + 4.0 * (n_own + 1) + 4.0 * (be.n_nodes_owned + 1) + 8.0 * n_own + 8.0 * n_loc
+    return b_node, b_csr
+
+
+def roofline_block(be, prof, workload, world):
+    spmv_ms, spmv_n = prof["spmv"]
+    b_node, b_csr = spmv_bytes(be)
+    node_kernel = os.environ.get("KNP_SPMV", "") != "csr"
+    b_alg = b_node if node_kernel else b_csr
+    if not (spmv_n > 0 and spmv_ms > 0):
+        return None
+    avg_s = spmv_ms * 1e-3 / spmv_n
+    ach = b_alg / avg_s / 1e9
+    in_cache = be.nnz * 8 < 200e6
+    roof = {"bound": "hbm", "kernel": "k_spmv_node (SpMV on A)" if node_kernel else "k_spmv<L,*,1> (CSR SpMV on A)",
+            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "traffic_source": None, "bytes_per_launch": b_alg, "csr_equivalent_bytes": b_csr, "csr_equivalent_GBs": b_csr / avg_s / 1e9,
+            "avg_launch_us": avg_s * 1e6, "launches": int(spmv_n), "working_set": "infinity-cache resident" if in_cache else "exceeds the infinity cache",
+            "note": ("the matrix of this case (%.0f MB) stays in the 256 MB Infinity Cache: the fraction is memory-system, not pure HBM, "
+                     "bandwidth -- see roofline_large for the out-of-cache figure" % (be.nnz * 8 / 1e6)) if in_cache
+                    else "matrix exceeds the Infinity Cache: HBM bandwidth"}
+    # HBM traffic per launch is a PMC quantity (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled per the
+    # gfx950 16-B-load correction): it cannot be collected inside this process, so it is read from the committed profile of this command
+    for fn in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
+            ent = pmc.get(workload, {})
+            hit = [v for k, v in ent.items() if "k_spmv_node" in k and k.rstrip().endswith(", 0>")]
+            if hit and node_kernel and world == 1:
+                roof["traffic"] = hit[0]["hbm_bytes_corrected"]
+                roof["traffic_source"] = "from_committed_profile: profiles/" + fn
+                break
+        except Exception:      # noqa: BLE001
+            pass
+    return roof
+
+
+def timed_run(case, args, world, dist, torch, steps, warmup, snapshot_at=None, allow_repeat=True, profile_mask=0x1):
+    """warmup untimed steps, then `steps` steps between barriers, repeated while the timed total is below MIN_TIMED_S."""
+    st = Stepper(case)
+    be = st.be
+    solver = case["solver"]
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    step_no = 0
-    its_all, reasons = [], []
-    for _ in range(args.warmup):
-        step_no += 1
-        it, rs = one_step(step_no)
-    if args.warmup == 0:
-        pass
+    snap = None
+    for _ in range(warmup):
+        st.step()
+        if snapshot_at is not None and st.i == snapshot_at:
+            ni, ne = solver.potential_norms()
+            snap = {"step": st.i, "phi_i": ni, "phi_e": ne, "phi_m": case["problem"].phi_m_prev.numpy().copy()}
     be.profile_reset()
-    be.profile_enable(0x1f if args.profile_all else 0x1)       # class 0 = SpMV on A (dominant kernel)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step_no += 1
-        it, rs = one_step(step_no)
-        its_all.append(it)
-        reasons.append(rs)
-    fence()
-    elapsed = time.perf_counter() - t0
+    be.profile_enable(profile_mask)
+    reps, its_all, reasons = [], [], []
+    total = 0.0
+    while True:
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            it, rs = st.step()
+            its_all.append(it)
+            reasons.append(rs)
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        reps.append(el)
+        total += el
+        if not allow_repeat or total >= MIN_TIMED_S or len(reps) >= MAX_REPS:
+            break
     prof = be.profile_get()
+    stats = be.stats()
     be.profile_enable(0)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    srt = sorted(reps)
+    med = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
+    return {"stepper": st, "elapsed": med, "reps": reps, "its": its_all, "reasons": reasons, "prof": prof, "stats": stats, "snap": snap}
 
+
+def main_case(args, world, rank, dist, torch):
+    """The headline measurement (+ CPU baseline and parity on rank 0 of a single-GPU run); returns (json dict, failure text or None)."""
+    # the parity snapshot is taken during warmup (never inside the timed region), at the last step the oracle sample covers
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    snap_at = min(args.warmup, args.cpu_steps + 1) if want_cpu and args.warmup >= 1 else None
+
+    case = build_case(args.workload, args, world, rank, args.warmup + args.steps * MAX_REPS)
+    run = timed_run(case, args, world, dist, torch, args.steps, args.warmup, snapshot_at=snap_at,
+                    allow_repeat=not args.no_repeat, profile_mask=0x1f if args.profile_all else 0x1)
+    be, solver = run["stepper"].be, case["solver"]
+    elapsed = run["elapsed"]
     n_dof = be.n_dof_global
     ms_per_step = 1e3 * elapsed / max(args.steps, 1)
     value = n_dof * args.steps / elapsed / 1e6
-
-    # ---- roofline of the dominant kernel (SpMV on the system matrix A), per launch, this rank -----------
-    # Bytes the kernel must move: the node-structured kernel reads the CSR value array
-    # (8 B/nnz) but only a 4-B neighbour index per node pair instead of a 4-B column index per entry.
-    spmv_ms, spmv_n = prof["spmv"]
-    n_own, n_loc = be.n_dof_owned, be.n_dof_local
-    b_csr = 12.0 * be.nnz + 4.0 * (n_own + 1) + 8.0 * n_own + 8.0 * n_loc          # SURVEY 8(d) CSR figure
-    node_kernel = os.environ.get("KNP_SPMV", "") != "csr"
-    b_node = 8.0 * be.nnz + 4.0 * be.n_pairs + 4.0 * (n_own + 1) + 4.0 * (be.n_nodes_owned + 1) + 8.0 * n_own + 8.0 * n_loc
-    b_alg = b_node if node_kernel else b_csr
-    roof = None
-    if spmv_n > 0 and spmv_ms > 0:
-        avg_s = spmv_ms * 1e-3 / spmv_n
-        ach = b_alg / avg_s / 1e9
-        roof = {"bound": "hbm", "kernel": "k_spmv_node (SpMV on A)" if node_kernel else "k_spmv<L,*,1> (CSR SpMV on A)",
-                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                "bytes_per_launch": b_alg, "csr_equivalent_bytes": b_csr, "csr_equivalent_GBs": b_csr / avg_s / 1e9,
-                "avg_launch_us": avg_s * 1e6, "launches": int(spmv_n),
-                "note": "working set of the 512^2 case (~150 MB matrix) largely stays in the 256 MB Infinity Cache"
-                        if be.nnz * 8 < 200e6 else "matrix exceeds the Infinity Cache"}
-        # HBM traffic per launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the gfx950
-        # 16-B-load correction + WRITE_SIZE; collected by `rocprofv3 --pmc` in separate runs of this command)
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            ent = pmc.get(args.workload, {})
-            hit = [v for k, v in ent.items() if k.startswith("void k_spmv_node") and k.endswith(", 0>")]
-            if hit and node_kernel and world == 1:
-                roof["traffic"] = hit[0]["hbm_bytes_corrected"]
-        except Exception:      # noqa: BLE001
-            pass
-
+    roof = roofline_block(be, run["prof"], args.workload, world)
     norms = solver.potential_norms()
+    n_steps_timed = len(run["its"])
+    per_it = {k: run["stats"][k] / max(sum(run["its"]), 1) for k in ("allreduces", "halos", "readbacks")}
+    out = {
+        "metric": "MDoF/s per implicit timestep (assembly+GMRES)",
+        "value": value, "unit": "MDoF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if (case["tissue"] and world > 1) else "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{case['what']}, 3 ions, {'HH+ATP+cotransporters' if args.models == 'ci' else 'passive membrane'}, "
+                               f"GMRES(30)+{'AMG on block-diagonal P' if case['pc'] in ('hypre', 'amg') else case['pc']}, rtol {args.rtol:g}",
+                   "n_dof": int(n_dof), "nnz": int(be.nnz_global), "mechanisms": args.models, "pc": case["pc"],
+                   "parallelism": f"dd{world}", "gmres_its_per_step": float(sum(run["its"])) / max(n_steps_timed, 1),
+                   "converged_all": bool(all(r > 0 for r in run["reasons"])),
+                   "phi_norms": [norms[0], norms[1]],
+                   "exchanges_per_gmres_iteration": per_it},
+        "timing": {"reps": len(run["reps"]), "steps_per_rep": args.steps, "ms_per_step_each_rep": [1e3 * r / max(args.steps, 1) for r in run["reps"]],
+                   "stat": "median of the repetitions" if len(run["reps"]) > 1 else "single bracket",
+                   "timed_total_s": sum(run["reps"])},
+        "roofline": roof,
+        "cpu_baseline": None, "parity": None, "roofline_large": None,
+        "kernel_classes_ms": {k: {"ms": v[0], "launches": v[1]} for k, v in run["prof"].items()} if args.profile_all else None,
+    }
+    fail = None
+    if not out["config"]["converged_all"]:
+        fail = "GMRES did not converge in every timed step"
 
-    # ---- CPU baseline: the oracle (NumPy/SciPy restatement, 1 core) on a bounded sample --------
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not mt:
-        cpu = cpu_baseline(kind, N, args.models, args.rtol, args.cpu_steps, args.pc, solver)
+    # ---- CPU baseline (oracle, 1 core; C++/OpenMP twin at 1 core and all cores) + parity of the GPU run against it ----
+    if want_cpu and not case["tissue"]:
+        cpu, par = cpu_baseline(case, args, solver, run["snap"])
+        out["cpu_baseline"], out["parity"] = cpu, par
+        if par is not None and not par["ok"]:
+            fail = f"GPU solution differs from the oracle beyond {PARITY_TOL:g}: {par}"
+    return out, fail
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = os.environ.get("KNP_DIST_BACKEND", "nccl")      # "gloo": rehearsal with several ranks on one GPU
+        dev_index = local_rank % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    else:
+        torch.cuda.set_device(0)
+
+    out, fail = main_case(args, world, rank, dist, torch)
+
+    # ---- out-of-cache roofline: the 10^7-DoF-per-GPU point, same process, every kernel class timed with HIP events ----
+    large = (args.large or "").lower()
+    if rank == 0 and world == 1 and large not in ("", "none") and large != args.workload:
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        out["roofline_large"] = large_block(args, torch, dist)
 
     if rank == 0:
-        out = {
-            "metric": "MDoF/s per implicit timestep (assembly+GMRES)",
-            "value": value, "unit": "MDoF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if (mt and world > 1) else "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{what}, "
-                                   f"3 ions, {'HH+ATP+cotransporters' if args.models == 'ci' else 'passive membrane'}, GMRES(30)+{'AMG on block-diagonal P' if args.pc in ('hypre', 'amg') else args.pc}, rtol {args.rtol:g}",
-                       "n_dof": int(n_dof), "nnz": int(be.nnz_global), "mechanisms": args.models, "pc": args.pc,
-                       "parallelism": f"dd{world}", "gmres_its_per_step": float(sum(its_all)) / max(len(its_all), 1),
-                       "converged_all": bool(all(r > 0 for r in reasons)),
-                       "phi_norms": [norms[0], norms[1]]},
-            "roofline": roof,
-            "cpu_baseline": cpu,
-            "kernel_classes_ms": {k: {"ms": v[0], "launches": v[1]} for k, v in prof.items()} if args.profile_all else None,
-        }
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if fail:
+        print("bench.py: " + fail, file=sys.stderr, flush=True)
+        sys.exit(3)
 
 
-def cpu_baseline(kind, N, models, rtol, steps, pc, solver):
-    """Oracle timed on the host: same mesh, same physics, same algorithm (GMRES(30), left PC, the same
-    AMG construction and cycle parameters, applied by the NumPy V-cycle), single thread."""
+def large_block(args, torch, dist):
+    """SpMV roofline and per-class times on a working set far beyond the 256 MB Infinity Cache (cube136: 10.4 M DoF,
+    nnz 3.9e8 = 3.1 GB of matrix values)."""
+    t0 = time.perf_counter()
+    a2 = argparse.Namespace(**vars(args))
+    a2.pc = "auto"
+    case = build_case(args.large, a2, 1, 0, 2 + args.large_steps)
+    run = timed_run(case, a2, 1, dist, torch, args.large_steps, 2, allow_repeat=False, profile_mask=0x1f)
+    be = run["stepper"].be
+    roof = roofline_block(be, run["prof"], args.large, 1)
+    ms = 1e3 * run["elapsed"] / max(args.large_steps, 1)
+    n_steps = max(args.large_steps, 1)
+    blk = {"workload": case["what"] + f", {case['pc']}", "n_dof": int(be.n_dof_global), "nnz": int(be.nnz_global), "steps": args.large_steps, "warmup": 2,
+           "ms_per_step": ms, "MDoF_per_s": be.n_dof_global / ms / 1e3, "gmres_its_per_step": float(sum(run["its"])) / n_steps,
+           "converged_all": bool(all(r > 0 for r in run["reasons"])),
+           "spmv": roof,
+           "kernel_classes_ms_per_step": {k: {"ms": v[0] / n_steps, "launches": v[1] / n_steps} for k, v in run["prof"].items()},
+           "note": "kernel classes are timed with HIP event pairs around each group of launches (serialises nothing, but adds event records: "
+                   "ms_per_step here is a few percent above an unprofiled run)",
+           "wall_s_incl_setup": None}
+    blk["wall_s_incl_setup"] = time.perf_counter() - t0
+    return blk
+
+
+def cpu_baseline(case, args, solver, snap):
+    """CPU legs, timed on this box's host cores on a bounded sample of the same workload:
+       "port"      the NumPy/SciPy oracle (same mesh, physics and algorithm: GMRES(30), left PC, the same AMG construction and cycle
+                   parameters applied by the NumPy V-cycle), single thread -- also the parity checker of the GPU run;
+       "port-omp"  the C/OpenMP twin of the per-step kernels (oracle/knpemi_cpu.c), at 1 thread and at all cores."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
     import knpemi_oracle as K
     from cgx_hip import amg
+    kind, N, models, rtol, pc = case["kind"], case["N"], args.models, args.rtol, case["pc"]
+    steps = args.cpu_steps
     os.environ.setdefault("OMP_NUM_THREADS", "1")
     mk = K.make_square if kind == "square" else K.make_cube
     mdl = K.CI_MODELS() if models == "ci" else [K.Model("passive", (4,))]
     o = mk(N, models=mdl)
     pre, post, deg = solver.amg_pre, solver.amg_post, solver.amg_cheby_degree
 
+    rnd = amg.fp32_stored if solver.amg_fp32 else (lambda h: h)     # operator values as the library stores them
+
     def fac(P):
         if pc == "btcc":
-            hk = amg.build_hierarchy(amg.restrict_to_fields(P, (0, 1, 2)), theta=solver.amg_theta, coarse_size=solver.amg_coarse_size)
-            hp = amg.build_hierarchy(amg.restrict_to_fields(P, (3,)), theta=solver.amg_theta, coarse_size=solver.amg_coarse_size)
+            hk = rnd(amg.build_hierarchy(amg.restrict_to_fields(P, (0, 1, 2)), theta=solver.amg_theta, coarse_size=solver.amg_coarse_size))
+            hp = rnd(amg.build_hierarchy(amg.restrict_to_fields(P, (3,)), theta=solver.amg_theta, coarse_size=solver.amg_coarse_size))
             return K.pc_btcc(o, hk, hp, pre, post, deg)
-        h = amg.build_hierarchy(P, theta=solver.amg_theta, coarse_size=solver.amg_coarse_size)
+        h = rnd(amg.build_hierarchy(P, theta=solver.amg_theta, coarse_size=solver.amg_coarse_size))
         return K.pc_amg_vcycle(h.levels, h.coarse_inv, pre, post, deg)
-    times = []
+    times, osnap = [], {}
 
     def log(step, oo, x):
         times.append(time.perf_counter())
+        if snap is not None and step == snap["step"]:
+            ni, ne = oo.potential_norms()
+            osnap.update(phi_i=ni, phi_e=ne, phi_m=np.array(oo.phi_m, copy=True))
     t_start = time.perf_counter()
     _, its = o.run(steps + 1, solver="gmres", pc=fac, rtol=rtol, log=log)
     per = [(times[i] - times[i - 1]) for i in range(1, len(times))]      # step 1 (null-space check, setup) excluded
     sec = sum(per) / len(per)
-    return {"value": o.n_dof / sec / 1e6, "unit": "MDoF/s", "cores": 1, "kind": "port",
-            "sample": f"{steps} implicit steps of the same {kind}{N} workload (NumPy/SciPy oracle: vectorised assembly, "
-                      f"GMRES(30)+{pc} with the NumPy V-cycle, {sum(its[1:]) / max(len(its) - 1, 1):.1f} its/step), "
-                      f"{sec:.2f} s/step; total {time.perf_counter() - t_start:.1f} s incl. setup"}
+    cpu = {"value": o.n_dof / sec / 1e6, "unit": "MDoF/s", "cores": 1, "kind": "port", "host_cores": os.cpu_count(),
+           "sample": f"{steps} implicit steps (steps 2..{steps + 1}) of the same {kind}{N} workload (NumPy/SciPy oracle: vectorised assembly, "
+                     f"GMRES(30)+{pc} with the NumPy V-cycle, {sum(its[1:]) / max(len(its) - 1, 1):.1f} its/step), "
+                     f"{sec:.2f} s/step; total {time.perf_counter() - t_start:.1f} s incl. setup",
+           "omp_twin": None}
+    try:
+        import knpemi_cpu_twin as T
+        cpu["omp_twin"] = T.time_kernels(o, budget_s=8.0)
+    except Exception as exc:      # noqa: BLE001  (the twin is an extra leg; its absence must not take the bench line down)
+        cpu["omp_twin"] = {"error": f"{type(exc).__name__}: {exc}"}
+    par = None
+    if snap is not None and osnap:
+        s = float(np.abs(osnap["phi_m"]).max())
+        par = {"step": snap["step"], "checker": "oracle GMRES with the same preconditioner algorithm, same rtol",
+               "rel_err_phi_i_L2": abs(snap["phi_i"] - osnap["phi_i"]) / osnap["phi_i"],
+               "rel_err_phi_e_L2": abs(snap["phi_e"] - osnap["phi_e"]) / osnap["phi_e"],
+               "rel_err_phi_m_max": float(np.abs(snap["phi_m"] - osnap["phi_m"]).max()) / s,
+               "tol": PARITY_TOL}
+        par["ok"] = bool(par["rel_err_phi_i_L2"] <= PARITY_TOL and par["rel_err_phi_m_max"] <= PARITY_TOL)
+    return cpu, par
 
 
 if __name__ == "__main__":

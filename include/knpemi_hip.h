@@ -276,6 +276,11 @@ int knp_l2_norms(knp_ctx* ctx, const double* phi_i, const double* phi_e, double*
 int knp_profile_enable(knp_ctx* ctx, int32_t class_mask); /* bit k enables class k; 0 disables */
 int knp_profile_get(knp_ctx* ctx, int32_t cls, double* ms, int64_t* launches);
 int knp_profile_reset(knp_ctx* ctx);
+/* counters of the linear solves since the last knp_profile_reset: what PETSc's -log_view reports for the KSPSolve stage
+ * (VecMDot/VecNorm reductions, VecScatter halos) behind KNPEMIx_solver.py:435 */
+enum { KNP_ST_BNORM = 0 /* ||B b|| of the last solve */, KNP_ST_ALLREDUCE = 1 /* reductions over ranks */,
+       KNP_ST_HALO = 2 /* fine-level halo exchanges */, KNP_ST_READBACK = 3 /* host waits on a reduced value */, KNP_ST_COUNT = 8 };
+int knp_get_stats(const knp_ctx* ctx, double* out /* host [KNP_ST_COUNT] */);
 
 #ifdef __cplusplus
 }

@@ -246,3 +246,23 @@ def upload(lib, ctx, check, hier: Hierarchy, pre: int = 1, post: int = 1, cheby_
     if hier.coarse_inv is not None:
         ci_ = np.ascontiguousarray(hier.coarse_inv, dtype=np.float64)
         check(lib.knp_amg_set_coarse(ctx, index, ci_.shape[0], fp(ci_)))
+
+
+def fp32_stored(h: Hierarchy) -> Hierarchy:
+    """The hierarchy as the library holds it with ``amg_fp32`` (default): level and transfer operator VALUES rounded to
+    fp32 (diagonals, vectors, arithmetic and the dense coarse inverse stay fp64).  For checkers that restate the V-cycle."""
+    import copy
+
+    def rnd(M):
+        if M is None:
+            return None
+        M = M.copy()
+        M.data = M.data.astype(np.float32).astype(np.float64)
+        return M
+    out = copy.copy(h)
+    out.levels = []
+    for lv in h.levels:
+        l2 = copy.copy(lv)
+        l2.A, l2.P, l2.R = rnd(lv.A), rnd(lv.P), rnd(lv.R)
+        out.levels.append(l2)
+    return out

@@ -238,6 +238,9 @@ struct knp_ctx {
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     const double* prep_b = nullptr;
+    // statistics of the solves (knp_get_stats): ||B b|| of the last solve, exchanges and host read-backs since the last reset
+    double last_bnorm = 0.0;
+    int64_t n_allreduce = 0, n_halo = 0, n_readback = 0;
     // profiling
     int prof_on = 0;
     struct ProfRec { hipEvent_t a, b; int cls; };

@@ -1600,6 +1600,14 @@ static int check_fields(knp_ctx* ctx, const knp_fields* f, bool need_phim) {
     return KNP_OK;
 }
 
+// cc = psi / (sum_j z_j^2 k_j) / M_lumped at every owned node (Schur term of the block-triangular preconditioner)
+static void launch_schur_diag(knp_ctx* ctx, const FieldPtrs& f) {
+    const KnpHostGraph& g = ctx->g;
+    hipLaunchKernelGGL(k_schur_diag, dim3(nblocks(g.n_nodes_owned)), dim3(NT), 0, ctx->stream, g.n_nodes_owned, ctx->psi, ctx->z[0], ctx->z[1],
+                       ctx->z[2], ctx->d_node_vertex, ctx->d_node_side, f, ctx->d_ML, ctx->d_cc);
+    ctx->have_cc = true;
+}
+
 int knp_assemble_matrix(knp_ctx* ctx, const knp_fields* fields) {
     CHECK_CTX(ctx);
     KCHK(check_fields(ctx, fields, false));
@@ -1644,9 +1652,9 @@ int knp_assemble_matrix(knp_ctx* ctx, const knp_fields* fields) {
     if (ctx->n_bc > 0)
         hipLaunchKernelGGL(k_dirichlet_rows_A, dim3(nblocks(ctx->n_bc)), dim3(NT), 0, ctx->stream, ctx->n_bc, ctx->d_bc_dofs, ctx->d_rowptr,
                            ctx->d_colind, ctx->d_vals);
-    hipLaunchKernelGGL(k_schur_diag, dim3(nblocks(g.n_nodes_owned)), dim3(NT), 0, ctx->stream, g.n_nodes_owned, ctx->psi, ctx->z[0], ctx->z[1],
-                       ctx->z[2], ctx->d_node_vertex, ctx->d_node_side, f, ctx->d_ML, ctx->d_cc);
-    ctx->have_cc = true;
+    // The Schur diagonal depends on the fields only.  knp_assemble_rhs of the same step has already written it; while a
+    // side-stream preconditioner application (knp_gmres_prepare) is in flight it READS d_cc, so it must not be rewritten here.
+    if (!ctx->prep_b) launch_schur_diag(ctx, f);
     HIPCHK(hipGetLastError());
     ctx->have_A = true;
     if (ctx->pc_kind == KNP_PC_VBJACOBI) {
@@ -1749,12 +1757,14 @@ int knp_assemble_rhs(knp_ctx* ctx, const knp_fields* fields, double* b) {
                        ctx->d_node_vertex, ctx->d_node_side, ctx->d_pair_ptr, ctx->d_pair_col, ctx->d_pair_M, f, src,
                        ctx->have_sources ? 1 : 0, ctx->d_node_gv, ctx->d_gdiag, ctx->d_gcptr, ctx->d_gc_facet, ctx->d_gc_lab,
                        ctx->d_fvec, b);
+    launch_schur_diag(ctx, f);   // before a possible knp_gmres_prepare forks the side stream (it reads d_cc)
     HIPCHK(hipGetLastError());
     return KNP_OK;
 }
 
 // ---- reductions: partial blocks -> d_red[slot], then (multi-GPU) all-reduce of a slot range ----
 static int allreduce_slots(knp_ctx* ctx, int slot0, int count) {
+    ++ctx->n_allreduce;   // counted on one GPU too: it is the number of reductions the algorithm needs
     if (ctx->p2p_red >= 0)   // native exchange: the summing kernel also fills the pinned mirror and publishes the sequence word
         return knp_p2p_allreduce(ctx, ctx->p2p_red, ctx->d_red + slot0, count, ctx->h_red_dev ? ctx->h_red_dev + slot0 : nullptr,
                                  ctx->h_red_dev ? ctx->h_seq_dev : nullptr, ++ctx->seq_counter);
@@ -1765,6 +1775,7 @@ static int allreduce_slots(knp_ctx* ctx, int slot0, int count) {
     return KNP_OK;
 }
 static int halo_update(knp_ctx* ctx, double* x) {
+    ++ctx->n_halo;
     if (ctx->p2p_fine >= 0) return knp_p2p_halo_forward(ctx, ctx->p2p_fine, x);
     if (ctx->halo) {
         int rc = ctx->halo(ctx->comm_user, x);
@@ -1781,6 +1792,7 @@ static int dot_to_slot(knp_ctx* ctx, const double* a, const double* b, int slot)
 }
 static int read_slots_inner(knp_ctx* ctx, int slot0, int count, int64_t wait_seq);
 static int read_slots(knp_ctx* ctx, int slot0, int count, int64_t wait_seq = 0) {
+    ++ctx->n_readback;
     KCHK(read_slots_inner(ctx, slot0, count, wait_seq));
     return ctx->p2p ? knp_p2p_check(ctx) : KNP_OK;   // a peer that never arrived: stop here, not after max_it iterations
 }
@@ -2394,7 +2406,9 @@ int knp_gmres_prepare(knp_ctx* ctx, const double* b) {
     side_discard(ctx);
     // single-GPU contexts only (the exchanges of a distributed preconditioner are ordered on the main stream), and only
     // once the Krylov workspace exists (second solve onwards)
-    static const bool off = getenv("KNP_NO_PREPARE") != nullptr;
+    const bool off = getenv("KNP_NO_PREPARE") != nullptr;
+    // vertex-block Jacobi takes its blocks from the matrix that knp_assemble_matrix is about to rewrite: nothing to overlap
+    if (ctx->pc_kind == KNP_PC_VBJACOBI) return KNP_OK;
     if (off || ctx->halo || ctx->allreduce || ctx->level_comm || ctx->p2p || ctx->gm_restart <= 0 || (ctx->prof_on & ~1)) return KNP_OK;
     if (!ctx->stream2) {
         HIPCHK(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
@@ -2449,6 +2463,7 @@ int knp_gmres_solve(knp_ctx* ctx, const double* b, double* x, double rtol, doubl
         KCHK(read_slots(ctx, 60, 1, ctx->seq_counter));
     }
     const double bnorm = std::sqrt(ctx->h_red[60]);
+    ctx->last_bnorm = bnorm;
     if (!std::isfinite(bnorm)) { *its = 0; *rnorm = bnorm; *reason = KNP_DIVERGED_NANORINF; return KNP_OK; }
     const double ttol = std::max(rtol * bnorm, atol);
     const double dtol = 1e5;
@@ -2632,6 +2647,16 @@ int knp_profile_reset(knp_ctx* ctx) {
     CHECK_CTX(ctx);
     KCHK(prof_collect(ctx));
     for (int i = 0; i < KNP_NPROF; ++i) { ctx->prof_ms[i] = 0; ctx->prof_n[i] = 0; }
+    ctx->n_allreduce = ctx->n_halo = ctx->n_readback = 0;
+    return KNP_OK;
+}
+int knp_get_stats(const knp_ctx* ctx, double* out) {
+    if (!ctx || !out) return KNP_E_ARG;
+    for (int i = 0; i < KNP_ST_COUNT; ++i) out[i] = 0.0;
+    out[KNP_ST_BNORM] = ctx->last_bnorm;
+    out[KNP_ST_ALLREDUCE] = (double)ctx->n_allreduce;
+    out[KNP_ST_HALO] = (double)ctx->n_halo;
+    out[KNP_ST_READBACK] = (double)ctx->n_readback;
     return KNP_OK;
 }
 

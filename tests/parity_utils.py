@@ -11,54 +11,7 @@ for p in (os.path.join(ROOT, "knp-emi-cgx_amd"), os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-# physics of reference src/CGx/KNPEMI/configs/tests/electric_potential_norms_iterative_solver.yaml
-CI_BASE = {
-    "problem_type": "KNP-EMI",
-    "quiet": True,
-    "dt": 0.000025,
-    "time_steps": 10,
-    "physical_constants": {"T": 300, "F": 96485, "R": 8.314},
-    "C_M": 0.02,
-    "cell_tag_file": "square32.xdmf",
-    "facet_tag_file": "square32_facets.xdmf",
-    "ics_tags": [1], "ecs_tags": [2], "boundary_tags": [3], "membrane_tags": [4],
-    "mesh_conversion_factor": 1e-6,
-    "initial_conditions": {"phi_m": -0.070, "Na_i": 12, "Na_e": 140, "K_i": 130, "K_e": 4, "Cl_i": 5, "Cl_e": 125,
-                           "n": 0.276, "m": 0.0379, "h": 0.688},
-    "stimulus": {"conductance": {"g_syn_bar": 1e-9}, "a_syn": 5e-4, "T_stim": 1.0, "scale": True},
-    "solver": {"direct": False,
-               "ksp_settings": {"strong_threshold": 0.5, "ksp_rtol": 1e-9, "ksp_type": "gmres", "pc_type": "hypre",
-                                "norm_type": "preconditioned", "non_zero_init_guess": True},
-               "output": {"save_xdmf": False, "save_cpoints": False, "save_pngs": False, "save_dat": False}},
-}
-
-
-def ci_config(N=32, steps=10, rtol=1e-9, pc="hypre", kind="square", direct=False):
-    cfg = copy.deepcopy(CI_BASE)
-    cfg["time_steps"] = steps
-    cfg["cell_tag_file"] = f"{kind}{N}.xdmf"
-    cfg["facet_tag_file"] = f"{kind}{N}_facets.xdmf"
-    cfg["solver"]["direct"] = direct
-    cfg["solver"]["ksp_settings"]["ksp_rtol"] = rtol
-    cfg["solver"]["ksp_settings"]["pc_type"] = pc
-    return cfg
-
-
-def make_problem(cfg, models="ci", local_mesh=None):
-    """Construction order of the reference's test scripts (tests/KNPEMI/electric_potential_norms_*.py:27-36)."""
-    from CGx.KNPEMI.KNPEMIx_ionic_model import ATPPump, HodgkinHuxley, NeuronalCotransporters, PassiveModel
-    from CGx.KNPEMI.KNPEMIx_problem import ProblemKNPEMI
-    problem = ProblemKNPEMI(cfg, local_mesh=local_mesh)
-    if models == "ci":
-        ionic_models = [NeuronalCotransporters(problem), HodgkinHuxley(problem), ATPPump(problem)]
-    elif models == "passive":
-        ionic_models = [PassiveModel(problem)]
-    else:
-        ionic_models = models(problem)
-    problem.set_initial_conditions()
-    problem.init_ionic_models(ionic_models)
-    problem.setup_variational_form()
-    return problem
+from cgx_hip.configs import CI_BASE, ci_config, make_problem, tissue_config  # noqa: E402,F401
 
 
 def run_native(cfg, models="ci", local_mesh=None):
@@ -128,41 +81,25 @@ def mms_config(dim=2, N=8, dt=1e-5, steps=1, rtol=1e-12):
                        "output": {"save_xdmf": False, "save_cpoints": False, "save_pngs": False, "save_dat": False}}}
 
 
-def fp32_stored(h):
-    """The hierarchy as the library holds it with ``amg_fp32`` (default): level, transfer and coarse-inverse
-    VALUES rounded to fp32 (diagonals, vectors, arithmetic and the dense coarse inverse stay fp64)."""
-    import copy
-    import numpy as np
-
-    def rnd(M):
-        if M is None:
-            return None
-        M = M.copy()
-        if hasattr(M, "data"):
-            M.data = M.data.astype(np.float32).astype(np.float64)
-            return M
-        return M.astype(np.float32).astype(np.float64)
-    out = copy.copy(h)
-    out.levels = []
-    for lv in h.levels:
-        l2 = copy.copy(lv)
-        l2.A, l2.P, l2.R = rnd(lv.A), rnd(lv.P), rnd(lv.R)
-        out.levels.append(l2)
-    return out
+from cgx_hip.amg import fp32_stored  # noqa: E402,F401
 
 
-def tissue_config(dim=2, N=16, m=2, steps=2, rtol=1e-11, pc="hypre", stimulus=True):
-    """Tissue surrogate (lattice of cells, one tag per cell = its membrane tag; the shape of the reference's
-    configs/5m/100c.yaml: ics_tags range, membrane tags = cell tags, stimulus restricted to an x-range)."""
-    cfg = copy.deepcopy(CI_BASE)
-    K = m ** dim
-    cells = list(range(2, 2 + K))
-    name = f"tissue{dim}d_{N}_{m}.xdmf"
-    cfg.update({"time_steps": steps, "cell_tag_file": name, "facet_tag_file": name,
-                "ics_tags": cells, "ecs_tags": [1], "membrane_tags": cells})
-    if stimulus:
-        cfg["stimulus_tags"] = cells
-        cfg["stimulus_region"] = {"direction": "x", "range": [0.0, 0.5]}
-    cfg["solver"]["ksp_settings"]["ksp_rtol"] = rtol
-    cfg["solver"]["ksp_settings"]["pc_type"] = pc
-    return cfg
+def oracle_gmres_same_algorithm(kind, N, steps, pc, rtol, solver, models="ci"):
+    """The oracle stepping with PETSc-style GMRES(30) and the SAME preconditioner algorithm as the native solver
+    (hierarchies rebuilt on the host with the solver's parameters, applied by the NumPy V-cycle, operator values rounded to fp32
+    like the library stores them).  Returns (oracle, iterations)."""
+    import knpemi_oracle as K
+    from cgx_hip import amg
+    o = make_oracle(N, kind, models)
+    pre, post, deg = solver.amg_pre, solver.amg_post, solver.amg_cheby_degree
+    rnd = fp32_stored if solver.amg_fp32 else (lambda h: h)
+
+    def fac(P):
+        if pc == "btcc":
+            hk = rnd(amg.build_hierarchy(amg.restrict_to_fields(P, (0, 1, 2)), theta=solver.amg_theta, coarse_size=solver.amg_coarse_size))
+            hp = rnd(amg.build_hierarchy(amg.restrict_to_fields(P, (3,)), theta=solver.amg_theta, coarse_size=solver.amg_coarse_size))
+            return K.pc_btcc(o, hk, hp, pre, post, deg)
+        h = rnd(amg.build_hierarchy(P, theta=solver.amg_theta, coarse_size=solver.amg_coarse_size))
+        return K.pc_amg_vcycle(h.levels, h.coarse_inv, pre, post, deg)
+    _, its = o.run(steps, solver="gmres", pc=fac, rtol=rtol)
+    return o, its

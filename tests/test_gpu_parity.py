@@ -163,7 +163,7 @@ def test_two_steps_match_oracle(pc):
         assert np.allclose(s.problem.wh[0][j].numpy()[vi], o.k[0][j][vi], rtol=1e-7)
         assert np.allclose(s.problem.wh[1][j].numpy()[ve], o.k[1][j][ve], rtol=1e-7)
     if pc == "hypre":
-        assert abs(ne - oe) <= 1e-4 * oe
+        assert abs(ne - oe) <= 1e-5 * oe          # rtol 1e-13 against sparse LU (smoke at rtol 1e-11 reaches 2.6e-6)
 
 
 @pytest.mark.parametrize("fp32", [True, False])
