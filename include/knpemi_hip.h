@@ -249,6 +249,12 @@ int knp_amg_set_level_prolongator(knp_ctx* ctx, int32_t hier, int32_t level, int
  * repl_n > 0 -> the next level is replicated on all ranks with repl_n unknowns */
 int knp_amg_set_level_mode(knp_ctx* ctx, int32_t hier, int32_t level, int32_t distributed, int32_t repl_n);
 int knp_amg_set_coarse(knp_ctx* ctx, int32_t hier, int32_t n, const double* dense_inverse /* host [n*n] row-major */);
+/* optional, per level with a coarser level below it: S = (I - c2 Dinv A) Pprol with c2 = 1 / (0.6 lambda_max), CSR with n_rows rows
+ * (HOST arrays, copied).  With S on every level, V(1,1) / Chebyshev degree 1 and level 0 on the library's own P
+ * (knp_amg_use_native_level0) the cycle runs in its fused form: pre-smoothing + residual as one gather, prolongation +
+ * post-smoothing as one gather per level (same operator as the unfused cycle; KNP_FUSED=0 selects the latter). */
+int knp_amg_set_level_smoothed(knp_ctx* ctx, int32_t hier, int32_t level, int32_t n_rows, const int32_t* S_rowptr, const int32_t* S_colind,
+                        const double* S_vals);
 /* level 0 == the library's own P (owned block): use its pair-major storage and node kernels instead of the uploaded
  * CSR. mode: 0 off, 1 all four fields, 2 ion fields only, 3 potential only */
 int knp_amg_use_native_level0(knp_ctx* ctx, int32_t hier, int32_t mode);
@@ -279,7 +285,8 @@ int knp_profile_reset(knp_ctx* ctx);
 /* counters of the linear solves since the last knp_profile_reset: what PETSc's -log_view reports for the KSPSolve stage
  * (VecMDot/VecNorm reductions, VecScatter halos) behind KNPEMIx_solver.py:435 */
 enum { KNP_ST_BNORM = 0 /* ||B b|| of the last solve */, KNP_ST_ALLREDUCE = 1 /* reductions over ranks */,
-       KNP_ST_HALO = 2 /* fine-level halo exchanges */, KNP_ST_READBACK = 3 /* host waits on a reduced value */, KNP_ST_COUNT = 8 };
+       KNP_ST_HALO = 2 /* fine-level halo exchanges */, KNP_ST_READBACK = 3 /* host waits on a reduced value */,
+       KNP_ST_FUSED = 4 /* bit h set: hierarchy h runs the fused V(1,1) cycle */, KNP_ST_COUNT = 8 };
 int knp_get_stats(const knp_ctx* ctx, double* out /* host [KNP_ST_COUNT] */);
 
 #ifdef __cplusplus

@@ -114,10 +114,25 @@ def _dist(agg_distance, level):
 
 
 class Level:
-    __slots__ = ("A", "dinv", "lambda_max", "P", "R")
+    """One level: operator A, inverse diagonal, lambda_max(D^-1 A), prolongator P, restrictor R = P^T and
+    S = (I - c2 D^-1 A) P with c2 = 1 / (0.6 lambda_max): prolongation followed by the post-smoothing step of the
+    V(1,1) / Chebyshev-degree-1 cycle, as ONE operator (the library's fused cycle applies it in one gather)."""
+    __slots__ = ("A", "dinv", "lambda_max", "P", "R", "S")
 
-    def __init__(self, A, dinv, lambda_max, P=None, R=None):
-        self.A, self.dinv, self.lambda_max, self.P, self.R = A, dinv, lambda_max, P, R
+    def __init__(self, A, dinv, lambda_max, P=None, R=None, S=None):
+        self.A, self.dinv, self.lambda_max, self.P, self.R, self.S = A, dinv, lambda_max, P, R, S
+
+
+def cheby_first_coefficient(lambda_max: float) -> float:
+    """1/theta of the smoothing interval [0.1, 1.1] * lambda_max: the coefficient of a degree-1 Chebyshev (= damped Jacobi) step"""
+    return 1.0 / (0.5 * (1.1 + 0.1) * lambda_max)
+
+
+def post_smoothed_prolongator(A, dinv, lambda_max, Pm, AP=None):
+    AP = (A @ Pm) if AP is None else AP
+    S = (Pm - sp.diags(cheby_first_coefficient(lambda_max) * dinv) @ AP).tocsr()
+    S.sort_indices()
+    return S
 
 
 class Hierarchy:
@@ -190,9 +205,10 @@ def build_hierarchy(P: sp.csr_matrix, theta: float = 0.08, max_levels: int = 12,
         Pm.sort_indices()
         R = Pm.T.tocsr()
         R.sort_indices()
-        Ac = (R @ (A @ Pm)).tocsr()
+        AP = (A @ Pm).tocsr()
+        Ac = (R @ AP).tocsr()
         Ac.sort_indices()
-        levels.append(Level(A, dinv, lam, Pm, R))
+        levels.append(Level(A, dinv, lam, Pm, R, post_smoothed_prolongator(A, dinv, lam, Pm, AP)))
         A = Ac
     coarse_inv = dense_pseudo_inverse(levels[-1].A) if levels[-1].A.shape[0] <= 6000 else None
     return Hierarchy(levels, coarse_inv)
@@ -240,6 +256,13 @@ def upload(lib, ctx, check, hier: Hierarchy, pre: int = 1, post: int = 1, cheby_
             check(lib.knp_amg_set_level(ctx, index, l, A.shape[0], A.shape[0], ip(rp), ip(ci), fp(va), fp(dinv),
                                         float(lv.lambda_max), lv.P.shape[1], ip(Prp), ip(Pci), fp(Pv),
                                         ip(Rrp), ip(Rci), fp(Rv)))
+            S = getattr(lv, "S", None)
+            if S is not None:
+                Srp = np.ascontiguousarray(S.indptr, dtype=np.int32)
+                Sci = np.ascontiguousarray(S.indices, dtype=np.int32)
+                Sv = np.ascontiguousarray(S.data, dtype=np.float64)
+                keep += [Srp, Sci, Sv]
+                check(lib.knp_amg_set_level_smoothed(ctx, index, l, S.shape[0], ip(Srp), ip(Sci), fp(Sv)))
         else:
             check(lib.knp_amg_set_level(ctx, index, l, A.shape[0], A.shape[0], ip(rp), ip(ci), fp(va), fp(dinv),
                                         float(lv.lambda_max), 0, None, None, None, None, None, None))
@@ -264,5 +287,6 @@ def fp32_stored(h: Hierarchy) -> Hierarchy:
     for lv in h.levels:
         l2 = copy.copy(lv)
         l2.A, l2.P, l2.R = rnd(lv.A), rnd(lv.P), rnd(lv.R)
+        l2.S = rnd(getattr(lv, "S", None))
         out.levels.append(l2)
     return out

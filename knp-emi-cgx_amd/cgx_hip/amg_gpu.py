@@ -236,8 +236,13 @@ def build_hierarchy(P, theta: float = 0.08, max_levels: int = 12, coarse_size: i
         Pm = _from_coo(torch.cat([T.rows(), rAFT]), torch.cat([T.col, AFT.col]),
                        torch.cat([T.val, -omega * dFinv[rAFT] * AFT.val]), (n, nagg), drop_zeros=True)
         R = _transpose(Pm)
-        Ac = _spgemm(R, _spgemm(A, Pm))
-        levels.append(amg.Level(A_host, dinv.cpu().numpy(), lam, Pm.scipy(), R.scipy()))
+        AP = _spgemm(A, Pm)
+        Ac = _spgemm(R, AP)
+        # S = (I - c2 Dinv A) Pm: prolongation + post-smoothing step of the fused cycle as one operator
+        rAP = AP.rows()
+        c2 = amg.cheby_first_coefficient(lam)
+        S = _from_coo(torch.cat([Pm.rows(), rAP]), torch.cat([Pm.col, AP.col]), torch.cat([Pm.val, -c2 * dinv[rAP] * AP.val]), (n, nagg))
+        levels.append(amg.Level(A_host, dinv.cpu().numpy(), lam, Pm.scipy(), R.scipy(), S.scipy()))
         A = Ac
         A_host = Ac.scipy()
     # the dense pseudo-inverse stays on the host (LAPACK): the device eigen-solver is not accurate enough for the nearly

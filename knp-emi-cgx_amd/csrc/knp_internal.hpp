@@ -115,6 +115,15 @@ struct KnpAmgLevel {
     double* R_v = nullptr;
     double *x = nullptr, *b = nullptr, *r = nullptr, *d = nullptr, *r2 = nullptr;  // work vectors (x / r2 ping-pong)
     int A_lanes = 8, P_lanes = 4, R_lanes = 8;
+    // fused cycle: S = (I - c2 Dinv A) Pprol, rows = this level's rows (compact list of the non-empty ones when S_n_act > 0)
+    int32_t *S_rp = nullptr, *S_ci = nullptr;
+    double* S_v = nullptr;
+    float* S_vf = nullptr;
+    int S_rows = 0, S_n_act = 0, S_lanes = 4;
+    int32_t *S_act_rows = nullptr, *S_act_rp = nullptr;
+    // level 0 of a potential-only hierarchy on compact vectors [n_nodes]: node indices instead of 4*node+3
+    int32_t *R_ci_c = nullptr, *S_act_rows_c = nullptr;
+    double* dinv_c = nullptr;
 };
 
 #define KNP_MAX_HIER 2
@@ -125,6 +134,10 @@ struct KnpAmgHier {
     int nc = 0;
     double* cinv = nullptr;
     float* cinv_f = nullptr;
+    // fused V(1,1) cycle (knp_pc_setup decides): Pt = P Dinv of level 0, fp64 or fp32, 4 fields per pair; potential part compact
+    int fused = 0;
+    double *pt = nullptr, *pt_phi = nullptr;
+    float *pt_f = nullptr, *pt_phi_f = nullptr;
 };
 
 struct knp_ctx {

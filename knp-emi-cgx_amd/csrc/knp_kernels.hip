@@ -61,6 +61,7 @@ struct FieldPtrs {
 };
 
 static void side_discard(knp_ctx* ctx);
+static void free_hier(KnpAmgHier& H);
 static inline int nblocks(int64_t n, int per = NT) { return (int)std::max<int64_t>(1, (n + per - 1) / per); }
 
 // ------------------------------------------------------------------------------------------
@@ -511,7 +512,7 @@ __global__ void __launch_bounds__(NT) k_to_float(int64_t n, const double* __rest
 //   k_schur_fin: z_phi = w_phi + cc * t_phi
 //   k_schur_diag: cc = psi / (sum_j z_j^2 k_j) / M_lumped  at every owned node
 // ------------------------------------------------------------------------------------------
-template <int G>
+template <int G, bool COMPACT>   // COMPACT: t is the potential right-hand side on node-indexed vectors [n_nodes] (fused cycle)
 __global__ void __launch_bounds__(NT)
 k_phi_rhs(int n_nodes, double z0, double z1, double z2, const int32_t* __restrict__ pair_ptr,
           const int32_t* __restrict__ pair_col, const double* __restrict__ pair_M, const double* __restrict__ r,
@@ -538,9 +539,27 @@ k_phi_rhs(int n_nodes, double z0, double z1, double z2, const int32_t* __restric
         const size_t i = 4 * (size_t)node;
         const double2 ra = *reinterpret_cast<const double2*>(r + i);
         const double2 rb = *reinterpret_cast<const double2*>(r + i + 2);
-        *reinterpret_cast<double2*>(t + i) = make_double2(0.0, 0.0);
-        *reinterpret_cast<double2*>(t + i + 2) = make_double2(0.0, rb.y - (z0 * ra.x + z1 * ra.y + z2 * rb.x) + s);
+        const double tphi = rb.y - (z0 * ra.x + z1 * ra.y + z2 * rb.x) + s;
+        if (COMPACT) {
+            t[node] = tphi;
+        } else {
+            *reinterpret_cast<double2*>(t + i) = make_double2(0.0, 0.0);
+            *reinterpret_cast<double2*>(t + i + 2) = make_double2(0.0, tphi);
+        }
     }
+}
+template <bool COMPACT>
+static void launch_phi_rhs(knp_ctx* ctx, const double* r, const double* z, double* t) {
+    const int G = ctx->pc_group, n = ctx->g.n_nodes_owned;
+    if (n <= 0) return;
+#define KNP_PR(GG) hipLaunchKernelGGL((k_phi_rhs<GG, COMPACT>), dim3(nblocks((int64_t)n * GG)), dim3(NT), 0, ctx->stream, n, ctx->z[0], ctx->z[1], ctx->z[2], ctx->d_pair_ptr, ctx->d_pair_col, ctx->d_pair_M, r, z, t)
+    switch (G) {
+        case 4: KNP_PR(4); break;
+        case 8: KNP_PR(8); break;
+        case 16: KNP_PR(16); break;
+        default: KNP_PR(32); break;
+    }
+#undef KNP_PR
 }
 __global__ void __launch_bounds__(NT) k_schur_fin(int n_nodes, const double* __restrict__ cc, const double* __restrict__ t,
                                                   const double* __restrict__ w, double* __restrict__ z) {
@@ -653,6 +672,152 @@ static void launch_restrict_first_t(hipStream_t st, int lanes, int n_rows, const
         case 32: hipLaunchKernelGGL((k_restrict_first<32, VT>), dim3(nblocks((int64_t)n_rows * 32)), dim3(NT), 0, st, n_rows, rp, ci, v, x, y, c, dinv, d, xo); break;
         default: hipLaunchKernelGGL((k_restrict_first<64, VT>), dim3(nblocks((int64_t)n_rows * 64)), dim3(NT), 0, st, n_rows, rp, ci, v, x, y, c, dinv, d, xo); break;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused V(1,1) legs (Chebyshev degree 1, zero initial guess).  With x0 = c Dinv b the pre-smoothing and the residual are
+//   down (level 0):    r = b - c Pt b,              Pt = P Dinv   (columns of the pair-major P scaled once, at setup)
+// and with S = (I - c2 Dinv A) Pprol (one sparse product at setup) the prolongation and the post-smoothing step are
+//   up   (any level):  x = x0 + c2 Dinv r + S xc
+// -- the same V-cycle, two gathers per level instead of four kernels, no intermediate iterate.
+// FM 0: all four fields, 1: ion fields (both on vectors with 4 unknowns per node), 2: potential on COMPACT vectors [n_nodes]
+// ------------------------------------------------------------------------------------------
+template <int G, int FM, typename VT>
+__global__ void __launch_bounds__(NT)
+k_l0_down(int n_nodes, const int32_t* __restrict__ pair_ptr, const int32_t* __restrict__ pair_col, const VT* __restrict__ pt,
+          const double* __restrict__ b, double c, double* __restrict__ r) {
+    const int node = (blockIdx.x * NT + threadIdx.x) / G;
+    const int lane = threadIdx.x & (G - 1);
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (node < n_nodes) {
+        const int p0 = pair_ptr[node];
+        const int deg = pair_ptr[node + 1] - p0;
+        for (int q = lane; q < deg; q += G) {
+            const int nb = pair_col[p0 + q];
+            if (FM == 2) {
+                s3 += (double)pt[p0 + q] * b[nb];
+            } else {
+                double a0, a1, a2, a3;
+                if (sizeof(VT) == 4) {
+                    const float4 pq = *reinterpret_cast<const float4*>(pt + 4 * (size_t)(p0 + q));
+                    a0 = pq.x; a1 = pq.y; a2 = pq.z; a3 = pq.w;
+                } else {
+                    const double2 u = *reinterpret_cast<const double2*>(pt + 4 * (size_t)(p0 + q));
+                    const double2 w = *reinterpret_cast<const double2*>(pt + 4 * (size_t)(p0 + q) + 2);
+                    a0 = u.x; a1 = u.y; a2 = w.x; a3 = w.y;
+                }
+                const double2 xa = *reinterpret_cast<const double2*>(b + 4 * (size_t)nb);
+                const double2 xb = *reinterpret_cast<const double2*>(b + 4 * (size_t)nb + 2);
+                s0 += a0 * xa.x;
+                s1 += a1 * xa.y;
+                s2 += a2 * xb.x;
+                if (FM == 0) s3 += a3 * xb.y;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = G >> 1; o > 0; o >>= 1) {
+        if (FM != 2) {
+            s0 += __shfl_xor(s0, o, G);
+            s1 += __shfl_xor(s1, o, G);
+            s2 += __shfl_xor(s2, o, G);
+        }
+        if (FM != 1) s3 += __shfl_xor(s3, o, G);
+    }
+    if (lane == 0 && node < n_nodes) {
+        if (FM == 2) {
+            r[node] = b[node] - c * s3;
+        } else {
+            const size_t i = 4 * (size_t)node;
+            const double2 b0 = *reinterpret_cast<const double2*>(b + i);
+            const double2 b1 = *reinterpret_cast<const double2*>(b + i + 2);
+            *reinterpret_cast<double2*>(r + i) = make_double2(b0.x - c * s0, b0.y - c * s1);
+            *reinterpret_cast<double2*>(r + i + 2) = make_double2(b1.x - c * s2, FM == 0 ? b1.y - c * s3 : 0.0);
+        }
+    }
+}
+template <int FM, typename VT>
+static void launch_l0_down_t(hipStream_t st, int G, int n_nodes, const int32_t* pp, const int32_t* pc, const VT* pt, const double* b, double c, double* r) {
+    if (n_nodes <= 0) return;
+    switch (G) {
+        case 4: hipLaunchKernelGGL((k_l0_down<4, FM, VT>), dim3(nblocks((int64_t)n_nodes * 4)), dim3(NT), 0, st, n_nodes, pp, pc, pt, b, c, r); break;
+        case 8: hipLaunchKernelGGL((k_l0_down<8, FM, VT>), dim3(nblocks((int64_t)n_nodes * 8)), dim3(NT), 0, st, n_nodes, pp, pc, pt, b, c, r); break;
+        case 16: hipLaunchKernelGGL((k_l0_down<16, FM, VT>), dim3(nblocks((int64_t)n_nodes * 16)), dim3(NT), 0, st, n_nodes, pp, pc, pt, b, c, r); break;
+        default: hipLaunchKernelGGL((k_l0_down<32, FM, VT>), dim3(nblocks((int64_t)n_nodes * 32)), dim3(NT), 0, st, n_nodes, pp, pc, pt, b, c, r); break;
+    }
+}
+template <typename VT>
+static void launch_l0_down(hipStream_t st, int fm, int G, int n_nodes, const int32_t* pp, const int32_t* pc, const VT* pt, const double* b, double c, double* r) {
+    if (fm == 2) launch_l0_down_t<2, VT>(st, G, n_nodes, pp, pc, pt, b, c, r);
+    else if (fm == 1) launch_l0_down_t<1, VT>(st, G, n_nodes, pp, pc, pt, b, c, r);
+    else launch_l0_down_t<0, VT>(st, G, n_nodes, pp, pc, pt, b, c, r);
+}
+
+// MODE 0: z[row] = x0 + c2 dinv r + S xc for the listed rows (rows == nullptr: all rows 0..n_act-1); x0 = xin[row] when xin is given,
+//         else c dinv b.   MODE 1: compact potential vectors (row = node): z[4 row + 3] = the same + cc[row] b[row]  (the
+//         Cahouet-Chabard Schur term of the block-triangular preconditioner, so that no separate kernel adds it)
+template <int L, typename VT, int MODE>
+__global__ void __launch_bounds__(NT)
+k_level_up(int n_act, const int32_t* __restrict__ rows, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
+           const VT* __restrict__ v, const double* __restrict__ xc, const double* __restrict__ dinv, const double* __restrict__ b,
+           const double* __restrict__ r, const double* xin, double c, double c2, double* z, const double* __restrict__ cc) {
+    const int gid = blockIdx.x * NT + threadIdx.x;
+    const int i = gid / L;
+    const int lane = threadIdx.x & (L - 1);
+    double s = 0.0;
+    if (i < n_act) {
+        const int e = rp[i + 1];
+        for (int k = rp[i] + lane; k < e; k += L) s += (double)v[k] * xc[ci[k]];
+    }
+#pragma unroll
+    for (int o = L >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, L);
+    if (lane == 0 && i < n_act) {
+        const int row = rows ? rows[i] : i;
+        const double di = dinv[row];
+        const double base = xin ? xin[row] : c * di * b[row];
+        const double out = base + c2 * di * r[row] + s;
+        if (MODE == 1) z[4 * (size_t)row + 3] = out + cc[row] * b[row];
+        else z[row] = out;
+    }
+}
+template <typename VT, int MODE>
+static void launch_level_up_t(hipStream_t st, int lanes, int n_act, const int32_t* rows, const int32_t* rp, const int32_t* ci, const VT* v,
+                              const double* xc, const double* dinv, const double* b, const double* r, const double* xin, double c, double c2,
+                              double* z, const double* cc) {
+    if (n_act <= 0) return;
+#define KNP_UP(LL) hipLaunchKernelGGL((k_level_up<LL, VT, MODE>), dim3(nblocks((int64_t)n_act * LL)), dim3(NT), 0, st, n_act, rows, rp, ci, v, xc, dinv, b, r, xin, c, c2, z, cc)
+    switch (lanes) {
+        case 2: KNP_UP(2); break;
+        case 4: KNP_UP(4); break;
+        case 8: KNP_UP(8); break;
+        case 16: KNP_UP(16); break;
+        case 32: KNP_UP(32); break;
+        default: KNP_UP(64); break;
+    }
+#undef KNP_UP
+}
+
+// setup helpers of the fused cycle
+//   Pt = P Dinv (pair-major, 4 fields per pair) and its compact potential part
+template <typename VT>
+__global__ void __launch_bounds__(NT)
+k_build_pt(int64_t n_pairs, const int32_t* __restrict__ pair_col, const double* __restrict__ pv, const double* __restrict__ dinv,
+           VT* __restrict__ pt, VT* __restrict__ pt_phi) {
+    for (int64_t p = (int64_t)blockIdx.x * NT + threadIdx.x; p < n_pairs; p += (int64_t)gridDim.x * NT) {
+        const int nb = pair_col[p];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const double val = pv[4 * p + f] * dinv[4 * (size_t)nb + f];
+            if (pt) pt[4 * p + f] = (VT)val;
+            if (f == 3 && pt_phi) pt_phi[p] = (VT)val;
+        }
+    }
+}
+__global__ void __launch_bounds__(NT) k_gather_stride4(int n, const double* __restrict__ in, int off, double* __restrict__ out) {
+    for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) out[i] = in[4 * (size_t)i + off];
+}
+__global__ void __launch_bounds__(NT) k_shift2(int64_t n, const int32_t* __restrict__ in, int32_t* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) out[i] = in[i] >> 2;
 }
 
 static int pick_lanes(double avg_nnz_per_row, int role = 0) {   // role 0 level operator, 1 prolongator, 2 restrictor
@@ -1370,17 +1535,7 @@ int knp_destroy(knp_ctx* ctx) {
     dev_free(ctx->d_V); dev_free(ctx->d_w); dev_free(ctx->d_t);
     for (auto& p : ctx->progs) { dev_free(p.d_code); dev_free(p.d_consts); if (p.h_consts) (void)hipHostFree(p.h_consts); }
     dev_free(ctx->d_prog_code); dev_free(ctx->d_prog_consts); dev_free(ctx->d_prog_len); dev_free(ctx->d_prog_nconsts);
-    for (int h = 0; h < KNP_MAX_HIER; ++h) {
-        KnpAmgHier& H = ctx->hier[h];
-        for (int l = 0; l < KNP_MAX_AMG_LEVELS; ++l) {
-            KnpAmgLevel& L = H.lv[l];
-            dev_free(L.A_rp); dev_free(L.A_ci); dev_free(L.A_v); dev_free(L.inv_diag);
-            dev_free(L.P_rp); dev_free(L.P_ci); dev_free(L.P_v); dev_free(L.R_rp); dev_free(L.R_ci); dev_free(L.R_v);
-            dev_free(L.A_vf); dev_free(L.P_vf); dev_free(L.R_vf); dev_free(L.P_act_rows); dev_free(L.P_act_rp); L.P_n_act = 0;
-            dev_free(L.x); dev_free(L.b); dev_free(L.r); dev_free(L.d); dev_free(L.r2);
-        }
-        dev_free(H.cinv); dev_free(H.cinv_f);
-    }
+    for (int h = 0; h < KNP_MAX_HIER; ++h) free_hier(ctx->hier[h]);
     dev_free(ctx->d_p_vals_f);
     dev_free(ctx->d_ML); dev_free(ctx->d_cc); dev_free(ctx->d_t2); dev_free(ctx->d_w2);
     dev_free(ctx->d_defl_mode); dev_free(ctx->d_defl_einv); dev_free(ctx->d_bc_dofs);
@@ -1935,10 +2090,14 @@ static void free_hier(KnpAmgHier& H) {
         dev_free(L.P_rp); dev_free(L.P_ci); dev_free(L.P_v); dev_free(L.R_rp); dev_free(L.R_ci); dev_free(L.R_v);
         dev_free(L.A_vf); dev_free(L.P_vf); dev_free(L.R_vf); dev_free(L.P_act_rows); dev_free(L.P_act_rp); L.P_n_act = 0;
         dev_free(L.x); dev_free(L.b); dev_free(L.r); dev_free(L.d); dev_free(L.r2);
+        dev_free(L.S_rp); dev_free(L.S_ci); dev_free(L.S_v); dev_free(L.S_vf); dev_free(L.S_act_rows); dev_free(L.S_act_rp);
+        dev_free(L.R_ci_c); dev_free(L.S_act_rows_c); dev_free(L.dinv_c);
+        L.S_rows = L.S_n_act = 0;
         L.n = L.n_coarse = 0;
     }
     dev_free(H.cinv); dev_free(H.cinv_f);
-    H.nc = 0; H.levels = 0; H.native0 = 0;
+    dev_free(H.pt); dev_free(H.pt_phi); dev_free(H.pt_f); dev_free(H.pt_phi_f);
+    H.nc = 0; H.levels = 0; H.native0 = 0; H.fused = 0;
 }
 int knp_amg_reset(knp_ctx* ctx, int32_t hier, int32_t n_levels, int32_t pre, int32_t post, int32_t cheby) {
     CHECK_CTX(ctx);
@@ -1951,19 +2110,22 @@ int knp_amg_reset(knp_ctx* ctx, int32_t hier, int32_t n_levels, int32_t pre, int
     return KNP_OK;
 }
 // compact row list of a prolongator when a good part of its rows is empty
-static int build_prolong_rows(knp_ctx* ctx, KnpAmgLevel& L, int n_rows_P, const int32_t* P_rp) {
-    dev_free(L.P_act_rows); dev_free(L.P_act_rp);
-    L.P_n_act = 0;
+static int build_act_rows(knp_ctx* ctx, int n_rows, const int32_t* rp_in, int32_t** d_rows, int32_t** d_rp, int* n_act) {
+    dev_free(*d_rows); dev_free(*d_rp);
+    *n_act = 0;
     std::vector<int32_t> rows, rp(1, 0);
-    for (int r = 0; r < n_rows_P; ++r)
-        if (P_rp[r + 1] > P_rp[r]) { rows.push_back(r); rp.push_back(P_rp[r + 1]); }
-    if ((double)rows.size() > 0.8 * n_rows_P || rows.empty()) return KNP_OK;   // dense enough: the plain kernel is fine
+    for (int r = 0; r < n_rows; ++r)
+        if (rp_in[r + 1] > rp_in[r]) { rows.push_back(r); rp.push_back(rp_in[r + 1]); }
+    if ((double)rows.size() > 0.8 * n_rows || rows.empty()) return KNP_OK;   // dense enough: the plain kernel is fine
     // non-empty rows are contiguous in the value array only if no empty row lies between entries -- they are: CSR rows are
     // consecutive, empty rows contribute nothing, so rp of the compact list is the running end pointer
-    KCHK(dev_upload(ctx, &L.P_act_rows, rows));
-    KCHK(dev_upload(ctx, &L.P_act_rp, rp));
-    L.P_n_act = (int)rows.size();
+    KCHK(dev_upload(ctx, d_rows, rows));
+    KCHK(dev_upload(ctx, d_rp, rp));
+    *n_act = (int)rows.size();
     return KNP_OK;
+}
+static int build_prolong_rows(knp_ctx* ctx, KnpAmgLevel& L, int n_rows_P, const int32_t* P_rp) {
+    return build_act_rows(ctx, n_rows_P, P_rp, &L.P_act_rows, &L.P_act_rp, &L.P_n_act);
 }
 
 int knp_amg_set_level(knp_ctx* ctx, int32_t hier, int32_t level, int32_t n_rows, int32_t n_cols_halo, const int32_t* A_rp,
@@ -2052,6 +2214,29 @@ int knp_amg_set_level_prolongator(knp_ctx* ctx, int32_t hier, int32_t level, int
     if (L.P_n_act > 0) L.P_lanes = pick_lanes((double)nnzP / L.P_n_act, 1);
     return KNP_OK;
 }
+int knp_amg_set_level_smoothed(knp_ctx* ctx, int32_t hier, int32_t level, int32_t n_rows, const int32_t* S_rp, const int32_t* S_ci, const double* S_v) {
+    CHECK_CTX(ctx);
+    if (hier < 0 || hier >= KNP_MAX_HIER || level < 0 || level >= ctx->hier[hier].levels) { ctx->err = "bad arguments"; return KNP_E_ARG; }
+    KnpAmgLevel& L = ctx->hier[hier].lv[level];
+    if (L.n_coarse <= 0 || !S_rp || !S_ci || !S_v || n_rows != L.n) { ctx->err = "S needs a level with a coarser level below it and one row per level row"; return KNP_E_ARG; }
+    const int64_t nnzS = S_rp[n_rows];
+    for (int64_t k = 0; k < nnzS; ++k)
+        if (S_ci[k] < 0 || S_ci[k] >= L.n_coarse) { ctx->err = "S column out of range"; return KNP_E_ARG; }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    dev_free(L.S_rp); dev_free(L.S_ci); dev_free(L.S_v); dev_free(L.S_vf);
+    KCHK(dev_upload_raw(ctx, &L.S_rp, S_rp, (size_t)n_rows + 1));
+    KCHK(dev_upload_raw(ctx, &L.S_ci, S_ci, (size_t)nnzS));
+    if (ctx->amg_fp32) {
+        std::vector<float> t(S_v, S_v + nnzS);
+        KCHK(dev_upload(ctx, &L.S_vf, t));
+    } else {
+        KCHK(dev_upload_raw(ctx, &L.S_v, S_v, (size_t)nnzS));
+    }
+    L.S_rows = n_rows;
+    KCHK(build_act_rows(ctx, n_rows, S_rp, &L.S_act_rows, &L.S_act_rp, &L.S_n_act));
+    L.S_lanes = pick_lanes((double)nnzS / std::max(L.S_n_act > 0 ? L.S_n_act : n_rows, 1), 1);
+    return KNP_OK;
+}
 int knp_amg_set_level_mode(knp_ctx* ctx, int32_t hier, int32_t level, int32_t distributed, int32_t repl_n) {
     CHECK_CTX(ctx);
     if (hier < 0 || hier >= KNP_MAX_HIER || level < 0 || level >= ctx->hier[hier].levels || repl_n < 0) { ctx->err = "bad arguments"; return KNP_E_ARG; }
@@ -2069,11 +2254,48 @@ int knp_amg_set_precision(knp_ctx* ctx, int32_t fp32_storage) {
     ctx->amg_fp32 = fp32_storage ? 1 : 0;   // takes effect for hierarchies uploaded afterwards
     return KNP_OK;
 }
+// level-0 data of the fused cycle: Pt = P Dinv with the hierarchy's own inverse diagonal (zero on the fields it does not act on);
+// potential-only hierarchies additionally get node-indexed copies of the index arrays that refer to level-0 rows
+static int build_fused_data(knp_ctx* ctx, KnpAmgHier& H) {
+    dev_free(H.pt); dev_free(H.pt_phi); dev_free(H.pt_f); dev_free(H.pt_phi_f);
+    KnpAmgLevel& L = H.lv[0];
+    dev_free(L.R_ci_c); dev_free(L.S_act_rows_c); dev_free(L.dinv_c);
+    if (!H.native0 || H.levels < 2 || !L.inv_diag || !L.S_rp) return KNP_OK;
+    const int64_t np = ctx->n_pairs;
+    const int nblk = (int)std::min<int64_t>(nblocks(np), 8192);
+    const bool phi = H.native0 == 3;
+    if (ctx->amg_fp32) {
+        if (phi) HIPCHK(hipMalloc((void**)&H.pt_phi_f, std::max<int64_t>(np, 1) * sizeof(float)));
+        else HIPCHK(hipMalloc((void**)&H.pt_f, std::max<int64_t>(4 * np, 1) * sizeof(float)));
+        hipLaunchKernelGGL((k_build_pt<float>), dim3(nblk), dim3(NT), 0, ctx->stream, np, ctx->d_pair_col, ctx->d_p_vals, L.inv_diag, H.pt_f, H.pt_phi_f);
+    } else {
+        if (phi) HIPCHK(hipMalloc((void**)&H.pt_phi, std::max<int64_t>(np, 1) * sizeof(double)));
+        else HIPCHK(hipMalloc((void**)&H.pt, std::max<int64_t>(4 * np, 1) * sizeof(double)));
+        hipLaunchKernelGGL((k_build_pt<double>), dim3(nblk), dim3(NT), 0, ctx->stream, np, ctx->d_pair_col, ctx->d_p_vals, L.inv_diag, H.pt, H.pt_phi);
+    }
+    if (phi) {
+        const int nn = ctx->g.n_nodes_owned;
+        HIPCHK(hipMalloc((void**)&L.dinv_c, std::max(nn, 1) * sizeof(double)));
+        hipLaunchKernelGGL(k_gather_stride4, dim3(std::min(nblocks(nn), 4096)), dim3(NT), 0, ctx->stream, nn, L.inv_diag, 3, L.dinv_c);
+        int32_t nnzR = 0;
+        HIPCHK(hipMemcpy(&nnzR, L.R_rp + L.n_coarse, sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIPCHK(hipMalloc((void**)&L.R_ci_c, std::max<size_t>(nnzR, 1) * sizeof(int32_t)));
+        hipLaunchKernelGGL(k_shift2, dim3(std::min<int64_t>(nblocks(nnzR), 4096)), dim3(NT), 0, ctx->stream, (int64_t)nnzR, L.R_ci, L.R_ci_c);
+        if (L.S_n_act > 0) {
+            HIPCHK(hipMalloc((void**)&L.S_act_rows_c, (size_t)L.S_n_act * sizeof(int32_t)));
+            hipLaunchKernelGGL(k_shift2, dim3(std::min<int64_t>(nblocks(L.S_n_act), 4096)), dim3(NT), 0, ctx->stream, (int64_t)L.S_n_act, L.S_act_rows, L.S_act_rows_c);
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return KNP_OK;
+}
+
 int knp_amg_use_native_level0(knp_ctx* ctx, int32_t hier, int32_t mode) {
     CHECK_CTX(ctx);
     if (hier < 0 || hier >= KNP_MAX_HIER || mode < 0 || mode > 3) { ctx->err = "bad arguments"; return KNP_E_ARG; }
     if (mode && !ctx->have_P) { ctx->err = "P not assembled"; return KNP_E_STATE; }
     ctx->hier[hier].native0 = mode;
+    KCHK(build_fused_data(ctx, ctx->hier[hier]));
     if (mode && ctx->amg_fp32) {   // fp32 shadow of the pair-major P for the level-0 node kernels
         const int64_t n = 4 * ctx->n_pairs;
         if (!ctx->d_p_vals_f) HIPCHK(hipMalloc((void**)&ctx->d_p_vals_f, std::max<int64_t>(n, 1) * sizeof(float)));
@@ -2243,6 +2465,78 @@ static double* amg_vcycle(knp_ctx* ctx, KnpAmgHier& H, int l, const double* b, d
     return cur;
 }
 
+// ---- fused V(1,1) cycle (see k_l0_down / k_level_up) -------------------------------------------------------------------
+// Eligible: level 0 on the library's own P (native0), V(1,1) with Chebyshev degree 1, S on every level above the last, no
+// distributed level, dense solve on the last level.  Anything else takes amg_vcycle.
+static bool fused_eligible(const knp_ctx* ctx, const KnpAmgHier& H) {
+    const bool off = getenv("KNP_FUSED") && atoi(getenv("KNP_FUSED")) == 0;   // read at every knp_pc_setup
+    if (off || !H.native0 || H.levels < 2 || H.cheby != 1 || H.pre != 1 || H.post != 1 || H.nc <= 0) return false;
+    if (!(H.pt || H.pt_f || H.pt_phi || H.pt_phi_f)) return false;
+    if (ctx->level_comm || ctx->p2p || ctx->halo) return false;
+    for (int l = 0; l < H.levels - 1; ++l) {
+        const KnpAmgLevel& L = H.lv[l];
+        if (!L.S_rp || L.dist || L.repl_n > 0 || L.S_rows != L.n) return false;
+    }
+    return true;
+}
+
+// z (level-0 rows of this hierarchy) = V-cycle applied to b.  Potential-only hierarchies (native0 == 3) take b on compact
+// node-indexed vectors and write z[4 node + 3] = cycle + cc[node] * b[node] (Schur term); the others work on 4 unknowns per node.
+static void amg_cycle_fused(knp_ctx* ctx, KnpAmgHier& H, const double* b, double* z) {
+    hipStream_t st = ctx->stream;
+    const int nl = H.levels;
+    const bool phi = H.native0 == 3;
+    const int fm = H.native0 == 1 ? 0 : H.native0 == 2 ? 1 : 2;
+    KnpAmgLevel& L0 = H.lv[0];
+    auto cheb_c = [](const KnpAmgLevel& L) { return 1.0 / (0.5 * (1.1 + 0.1) * L.lambda_max); };   // 1/theta of the smoothing interval
+    // level 0, down: r0 = b - c Pt b
+    const double c0 = cheb_c(L0);
+    const int nn = ctx->g.n_nodes_owned;
+    if (phi) {
+        if (H.pt_phi_f) launch_l0_down<float>(st, 2, ctx->pc_group, nn, ctx->d_pair_ptr, ctx->d_pair_col, H.pt_phi_f, b, c0, L0.r);
+        else launch_l0_down<double>(st, 2, ctx->pc_group, nn, ctx->d_pair_ptr, ctx->d_pair_col, H.pt_phi, b, c0, L0.r);
+    } else {
+        if (H.pt_f) launch_l0_down<float>(st, fm, ctx->pc_group, nn, ctx->d_pair_ptr, ctx->d_pair_col, H.pt_f, b, c0, L0.r);
+        else launch_l0_down<double>(st, fm, ctx->pc_group, nn, ctx->d_pair_ptr, ctx->d_pair_col, H.pt, b, c0, L0.r);
+    }
+    // down the hierarchy
+    for (int l = 0; l < nl - 1; ++l) {
+        KnpAmgLevel& L = H.lv[l];
+        KnpAmgLevel& C = H.lv[l + 1];
+        const int nc = L.n_coarse;
+        const int32_t* Rci = (l == 0 && phi) ? L.R_ci_c : L.R_ci;
+        if (l + 1 == nl - 1) {   // coarsest: b_c = R r ; x_c = Cinv b_c
+            if (L.R_vf) launch_spmv_t<0, 0, float>(st, L.R_lanes, nc, L.R_rp, Rci, L.R_vf, L.r, nullptr, C.b);
+            else launch_spmv_t<0, 0, double>(st, L.R_lanes, nc, L.R_rp, Rci, L.R_v, L.r, nullptr, C.b);
+            hipLaunchKernelGGL((k_dense_matvec<double>), dim3(nblocks((int64_t)H.nc * 64)), dim3(NT), 0, st, H.nc, H.cinv, C.b, C.x);
+        } else {                 // b_c = R r ; x_c = c Dinv b_c (first Chebyshev step, fused) ; r_c = b_c - A_c x_c
+            const double cc = cheb_c(C);
+            if (L.R_vf) launch_restrict_first_t<float>(st, L.R_lanes, nc, L.R_rp, Rci, L.R_vf, L.r, C.b, cc, C.inv_diag, C.d, C.x);
+            else launch_restrict_first_t<double>(st, L.R_lanes, nc, L.R_rp, Rci, L.R_v, L.r, C.b, cc, C.inv_diag, C.d, C.x);
+            launch_spmv_mp<1>(st, C.A_lanes, C.n, C.A_rp, C.A_ci, C.A_v, C.A_vf, C.x, C.b, C.r);
+        }
+    }
+    // up: x_l = x_l + c2 Dinv r_l + S x_{l+1}
+    for (int l = nl - 2; l >= 0; --l) {
+        KnpAmgLevel& L = H.lv[l];
+        KnpAmgLevel& C = H.lv[l + 1];
+        const double c = cheb_c(L);
+        const int n_act = L.S_n_act > 0 ? L.S_n_act : L.S_rows;
+        const int32_t* rp = L.S_n_act > 0 ? L.S_act_rp : L.S_rp;
+        if (l > 0) {
+            if (L.S_vf) launch_level_up_t<float, 0>(st, L.S_lanes, n_act, L.S_n_act > 0 ? L.S_act_rows : nullptr, rp, L.S_ci, L.S_vf, C.x, L.inv_diag, L.b, L.r, L.x, c, c, L.x, nullptr);
+            else launch_level_up_t<double, 0>(st, L.S_lanes, n_act, L.S_n_act > 0 ? L.S_act_rows : nullptr, rp, L.S_ci, L.S_v, C.x, L.inv_diag, L.b, L.r, L.x, c, c, L.x, nullptr);
+        } else if (phi) {
+            const int32_t* rows = L.S_n_act > 0 ? L.S_act_rows_c : nullptr;
+            if (L.S_vf) launch_level_up_t<float, 1>(st, L.S_lanes, L.S_n_act > 0 ? n_act : nn, rows, rp, L.S_ci, L.S_vf, C.x, L.dinv_c, b, L.r, nullptr, c, c, z, ctx->d_cc);
+            else launch_level_up_t<double, 1>(st, L.S_lanes, L.S_n_act > 0 ? n_act : nn, rows, rp, L.S_ci, L.S_v, C.x, L.dinv_c, b, L.r, nullptr, c, c, z, ctx->d_cc);
+        } else {
+            if (L.S_vf) launch_level_up_t<float, 0>(st, L.S_lanes, n_act, L.S_n_act > 0 ? L.S_act_rows : nullptr, rp, L.S_ci, L.S_vf, C.x, L.inv_diag, b, L.r, nullptr, c, c, z, nullptr);
+            else launch_level_up_t<double, 0>(st, L.S_lanes, n_act, L.S_n_act > 0 ? L.S_act_rows : nullptr, rp, L.S_ci, L.S_v, C.x, L.inv_diag, b, L.r, nullptr, c, c, z, nullptr);
+        }
+    }
+}
+
 static int check_hier(knp_ctx* ctx, int h) {
     KnpAmgHier& H = ctx->hier[h];
     if (H.levels < 1 || H.lv[0].n != ctx->n_dof_owned) { ctx->err = "AMG hierarchy " + std::to_string(h) + " not supplied"; return KNP_E_STATE; }
@@ -2271,6 +2565,13 @@ int knp_pc_setup(knp_ctx* ctx, int32_t kind) {
         }
     }
     ctx->pc_kind = kind;
+    for (int h = 0; h < KNP_MAX_HIER; ++h) ctx->hier[h].fused = 0;
+    if (kind == KNP_PC_AMG) ctx->hier[0].fused = fused_eligible(ctx, ctx->hier[0]) ? 1 : 0;
+    if (kind == KNP_PC_AMG_BT) {   // both or none: the potential hierarchy then works on compact vectors
+        const bool ok = fused_eligible(ctx, ctx->hier[0]) && fused_eligible(ctx, ctx->hier[1]) && ctx->hier[1].native0 == 3 && ctx->hier[0].native0 == 2 &&
+                        ctx->hier[1].lv[0].S_n_act > 0 && ctx->hier[1].lv[0].S_act_rows_c && ctx->hier[1].lv[0].R_ci_c;
+        ctx->hier[0].fused = ctx->hier[1].fused = ok ? 1 : 0;
+    }
     if (kind == KNP_PC_VBJACOBI && ctx->have_A) {
         const KnpHostGraph& g = ctx->g;
         hipLaunchKernelGGL(k_vbj_extract, dim3(nblocks(g.n_nodes_owned)), dim3(NT), 0, ctx->stream, g.n_nodes_owned,
@@ -2288,7 +2589,11 @@ __global__ void __launch_bounds__(NT) k_bc_copy(int n_bc, const int32_t* __restr
     const int i = blockIdx.x * NT + threadIdx.x;
     if (i >= n_bc) return;
     const int d = bc_dofs[i];
-    if (!phi_only || (d & 3) == 3) dst[d] = src[d];
+    if (phi_only == 2) {   // destination is a node-indexed potential vector
+        if ((d & 3) == 3) dst[d >> 2] = src[d];
+    } else if (!phi_only || (d & 3) == 3) {
+        dst[d] = src[d];
+    }
 }
 
 static int pc_apply_proj(knp_ctx* ctx, const double* r, double* z, int64_t cnt) {
@@ -2312,6 +2617,7 @@ static int pc_apply_proj(knp_ctx* ctx, const double* r, double* z, int64_t cnt) 
                                    ctx->d_node_side, ctx->d_node_gv, ctx->d_gv_node_e, ctx->d_vbj, r, z);
                 break;
             case KNP_PC_AMG: {
+                if (ctx->hier[0].fused) { amg_cycle_fused(ctx, ctx->hier[0], r, z); break; }
                 double* out = amg_vcycle(ctx, ctx->hier[0], 0, r, z);
                 if (out != z) HIPCHK(hipMemcpyAsync(z, out, (size_t)ctx->n_dof_owned * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
                 break;
@@ -2319,16 +2625,18 @@ static int pc_apply_proj(knp_ctx* ctx, const double* r, double* z, int64_t cnt) 
             case KNP_PC_AMG_BT: {
                 // z_k = V_k r_k ; t_phi = r_phi - A_{phi k} z_k ; z_phi = V_phi t_phi + cc * t_phi
                 if (!ctx->have_A || !ctx->have_cc) { ctx->err = "block-triangular preconditioner needs an assembled matrix"; return KNP_E_STATE; }
-                const int G = ctx->pc_group;
+                if (ctx->hier[0].fused) {
+                    amg_cycle_fused(ctx, ctx->hier[0], r, z);                 // ion entries of z
+                    launch_phi_rhs<true>(ctx, r, z, ctx->d_t2);               // t_phi on node-indexed vectors
+                    if (ctx->n_bc > 0)
+                        hipLaunchKernelGGL(k_bc_copy, dim3(nblocks(ctx->n_bc)), dim3(NT), 0, ctx->stream, ctx->n_bc, ctx->d_bc_dofs, r, ctx->d_t2, 2);
+                    amg_cycle_fused(ctx, ctx->hier[1], ctx->d_t2, z);         // z_phi = V_phi t + cc t
+                    break;
+                }
                 double* out = amg_vcycle(ctx, ctx->hier[0], 0, r, z);
                 if (out != z) HIPCHK(hipMemcpyAsync(z, out, (size_t)ctx->n_dof_owned * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
                 KCHK(halo_update(ctx, z));   // the mass-matrix row may reach ghost ion unknowns
-                switch (G) {
-                    case 4: hipLaunchKernelGGL((k_phi_rhs<4>), dim3(nblocks((int64_t)g.n_nodes_owned * 4)), dim3(NT), 0, ctx->stream, g.n_nodes_owned, ctx->z[0], ctx->z[1], ctx->z[2], ctx->d_pair_ptr, ctx->d_pair_col, ctx->d_pair_M, r, z, ctx->d_t2); break;
-                    case 8: hipLaunchKernelGGL((k_phi_rhs<8>), dim3(nblocks((int64_t)g.n_nodes_owned * 8)), dim3(NT), 0, ctx->stream, g.n_nodes_owned, ctx->z[0], ctx->z[1], ctx->z[2], ctx->d_pair_ptr, ctx->d_pair_col, ctx->d_pair_M, r, z, ctx->d_t2); break;
-                    case 16: hipLaunchKernelGGL((k_phi_rhs<16>), dim3(nblocks((int64_t)g.n_nodes_owned * 16)), dim3(NT), 0, ctx->stream, g.n_nodes_owned, ctx->z[0], ctx->z[1], ctx->z[2], ctx->d_pair_ptr, ctx->d_pair_col, ctx->d_pair_M, r, z, ctx->d_t2); break;
-                    default: hipLaunchKernelGGL((k_phi_rhs<32>), dim3(nblocks((int64_t)g.n_nodes_owned * 32)), dim3(NT), 0, ctx->stream, g.n_nodes_owned, ctx->z[0], ctx->z[1], ctx->z[2], ctx->d_pair_ptr, ctx->d_pair_col, ctx->d_pair_M, r, z, ctx->d_t2); break;
-                }
+                launch_phi_rhs<false>(ctx, r, z, ctx->d_t2);
                 if (ctx->n_bc > 0)   // pinned potentials: no Schur coupling, their right-hand side is the residual itself
                     hipLaunchKernelGGL(k_bc_copy, dim3(nblocks(ctx->n_bc)), dim3(NT), 0, ctx->stream, ctx->n_bc, ctx->d_bc_dofs, r, ctx->d_t2, 1);
                 double* w = amg_vcycle(ctx, ctx->hier[1], 0, ctx->d_t2, ctx->d_w2);
@@ -2657,6 +2965,7 @@ int knp_get_stats(const knp_ctx* ctx, double* out) {
     out[KNP_ST_ALLREDUCE] = (double)ctx->n_allreduce;
     out[KNP_ST_HALO] = (double)ctx->n_halo;
     out[KNP_ST_READBACK] = (double)ctx->n_readback;
+    out[KNP_ST_FUSED] = (double)(ctx->hier[0].fused + 2 * ctx->hier[1].fused);
     return KNP_OK;
 }
 

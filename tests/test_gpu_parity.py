@@ -418,3 +418,38 @@ def test_side_stream_prenorm_changes_nothing():
     b = _run_in_subprocess({"KNP_NO_PREPARE": "1"})
     assert a["its"] == b["its"]
     assert a["sum"] == b["sum"] and a["l1"] == b["l1"]
+
+
+@pytest.mark.parametrize("fp32", [False, True])
+@pytest.mark.parametrize("kind,N,pc,flags", [("square", 32, "hypre", 1), ("cube", 8, "btcc", 3), ("square", 24, "btcc", 3)])
+def test_fused_cycle_is_the_same_operator_as_the_unfused_cycle(kind, N, pc, flags, fp32, monkeypatch):
+    """The fused V(1,1) cycle (pre-smoothing + residual as one gather with P Dinv; prolongation + post-smoothing as one
+    gather with S = (I - c2 Dinv A) P; potential hierarchy on node-indexed vectors) applies the same linear operator as
+    the level-by-level cycle: identical up to rounding with fp64 storage, up to fp32 rounding of S vs (A, P) otherwise."""
+    from CGx.KNPEMI.KNPEMIx_solver import SolverKNPEMI
+    cfg = ci_config(N=N, steps=1, rtol=1e-9, kind=kind, pc=pc)
+    cfg["solver"]["ksp_settings"]["amg_coarse_size"] = 150
+    cfg["solver"]["ksp_settings"]["amg_fp32"] = fp32
+    p = make_problem(cfg)
+    s = SolverKNPEMI(p, solver_config=p.solver_config)
+    s.setup_solver()
+    be = s.backend
+    p.setup_preconditioner(s.use_block_Jacobi)
+    s.assemble_preconditioner()
+    be.assemble_rhs()
+    be.assemble_matrix()
+    be.pc_setup(s._pc_kind)
+    assert be.stats()["fused"] == flags
+    rng = np.random.default_rng(3)
+    r = torch.as_tensor(rng.standard_normal(be.n_dof_owned), device=be.device)
+    z1 = torch.zeros_like(r)
+    be.pc_apply(r, z1)
+    monkeypatch.setenv("KNP_FUSED", "0")
+    be.pc_setup(s._pc_kind)
+    assert be.stats()["fused"] == 0
+    z0 = torch.zeros_like(r)
+    be.pc_apply(r, z0)
+    z0, z1 = z0.cpu().numpy(), z1.cpu().numpy()
+    tol = 2e-6 if fp32 else 1e-12
+    for f in range(4):
+        assert np.max(np.abs(z1[f::4] - z0[f::4])) <= tol * np.max(np.abs(z0[f::4])), f
