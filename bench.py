@@ -400,14 +400,15 @@ def cpu_baseline(case, args, solver, snap):
     pre, post, deg = solver.amg_pre, solver.amg_post, solver.amg_cheby_degree
 
     rnd = amg.fp32_stored if solver.amg_fp32 else (lambda h: h)     # operator values as the library stores them
+    fused = bool(solver.backend.stats()["fused"])                    # ... and the order in which its cycle evaluates them
 
     def fac(P):
         if pc == "btcc":
             hk = rnd(amg.build_hierarchy(amg.restrict_to_fields(P, (0, 1, 2)), theta=solver.amg_theta, coarse_size=solver.amg_coarse_size))
             hp = rnd(amg.build_hierarchy(amg.restrict_to_fields(P, (3,)), theta=solver.amg_theta, coarse_size=solver.amg_coarse_size))
-            return K.pc_btcc(o, hk, hp, pre, post, deg)
+            return K.pc_btcc(o, hk, hp, pre, post, deg, fused=fused)
         h = rnd(amg.build_hierarchy(P, theta=solver.amg_theta, coarse_size=solver.amg_coarse_size))
-        return K.pc_amg_vcycle(h.levels, h.coarse_inv, pre, post, deg)
+        return K.pc_amg_vcycle(h.levels, h.coarse_inv, pre, post, deg, fused=fused)
     times, osnap = [], {}
 
     def log(step, oo, x):

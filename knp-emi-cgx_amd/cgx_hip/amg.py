@@ -117,10 +117,11 @@ class Level:
     """One level: operator A, inverse diagonal, lambda_max(D^-1 A), prolongator P, restrictor R = P^T and
     S = (I - c2 D^-1 A) P with c2 = 1 / (0.6 lambda_max): prolongation followed by the post-smoothing step of the
     V(1,1) / Chebyshev-degree-1 cycle, as ONE operator (the library's fused cycle applies it in one gather)."""
-    __slots__ = ("A", "dinv", "lambda_max", "P", "R", "S")
+    __slots__ = ("A", "dinv", "lambda_max", "P", "R", "S", "Pt")
 
     def __init__(self, A, dinv, lambda_max, P=None, R=None, S=None):
         self.A, self.dinv, self.lambda_max, self.P, self.R, self.S = A, dinv, lambda_max, P, R, S
+        self.Pt = None      # A Dinv as stored by the library on level 0 (filled by fp32_stored for checkers)
 
 
 def cheby_first_coefficient(lambda_max: float) -> float:
@@ -289,4 +290,7 @@ def fp32_stored(h: Hierarchy) -> Hierarchy:
         l2.A, l2.P, l2.R = rnd(lv.A), rnd(lv.P), rnd(lv.R)
         l2.S = rnd(getattr(lv, "S", None))
         out.levels.append(l2)
+    if out.levels:      # level 0 of the fused cycle applies Pt = A Dinv, computed in fp64 from the fp64 P and rounded once
+        l0 = h.levels[0]
+        out.levels[0].Pt = rnd((l0.A @ sp.diags(l0.dinv)).tocsr())
     return out

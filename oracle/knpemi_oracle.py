@@ -904,7 +904,7 @@ def pc_exact_lu():
     return factory
 
 
-def pc_amg_vcycle(levels, coarse_inv, pre=1, post=1, cheby_degree=2):
+def pc_amg_vcycle(levels, coarse_inv, pre=1, post=1, cheby_degree=2, fused=False):
     """NumPy restatement of the V-cycle the HIP library applies (knp_kernels.hip: amg_vcycle /
     amg_smooth).  ``levels`` = list of objects with .A (csr), .dinv, .lambda_max, .P, .R; the
     hierarchy itself is *data* produced by the host setup and is passed in by the test.
@@ -948,18 +948,57 @@ def pc_amg_vcycle(levels, coarse_inv, pre=1, post=1, cheby_degree=2):
             x = smooth(lv, b, x, False)
         return x
 
+    if fused:
+        return pc_amg_vcycle_fused(levels, coarse_inv)
     return lambda r: cycle(0, r)
 
 
-def pc_btcc(o, hier_k, hier_p, pre=1, post=1, cheby_degree=2, bc_dofs=None):
+def pc_amg_vcycle_fused(levels, coarse_inv):
+    """The same V(1,1) / Chebyshev-degree-1 cycle in the order the library's FUSED form evaluates it
+    (knp_kernels.hip: amg_cycle_fused): with x0 = c Dinv b,
+        level 0 down:  r = b - c Pt b,  Pt = A Dinv           (levels[0].Pt when the test supplies the stored values)
+        level l down:  x = c Dinv b ; r = b - A x
+        up:            x <- x + c Dinv r + S x_coarse,  S = (I - c Dinv A) Pprol   (levels[l].S)
+    Algebraically identical to pc_amg_vcycle(levels, coarse_inv, 1, 1, 1); the rounding of operators stored in fp32 (Pt, S
+    instead of A, P) is what differs, and is what the iterate-parity tests need to reproduce."""
+    assert coarse_inv is not None
+    nl = len(levels)
+    c = [1.0 / (0.5 * (1.1 + 0.1) * lv.lambda_max) for lv in levels]
+
+    def apply(b):
+        bs, rs, xs = [b], [], []
+        lv = levels[0]
+        Pt = getattr(lv, "Pt", None)
+        if Pt is None:
+            Pt = lv.A @ sp.diags(lv.dinv)
+        rs.append(b - c[0] * (Pt @ b))
+        xs.append(c[0] * lv.dinv * b)
+        for l in range(nl - 1):
+            bc = levels[l].R @ rs[l]
+            bs.append(bc)
+            if l + 1 == nl - 1:
+                xs.append(coarse_inv @ bc)
+            else:
+                C = levels[l + 1]
+                xc = c[l + 1] * C.dinv * bc
+                xs.append(xc)
+                rs.append(bc - C.A @ xc)
+        for l in range(nl - 2, -1, -1):
+            lv = levels[l]
+            xs[l] = xs[l] + c[l] * lv.dinv * rs[l] + lv.S @ xs[l + 1]
+        return xs[0]
+    return apply
+
+
+def pc_btcc(o, hier_k, hier_p, pre=1, post=1, cheby_degree=2, bc_dofs=None, fused=False):
     """NumPy restatement of the library's block lower-triangular preconditioner (KNP_PC_AMG_BT):
         z_k   = V_k r                                         (V-cycle of the ion-field hierarchy)
         t_phi = r_phi - sum_j z_j r_kj + M (sum_j z_j z_kj)   (== r_phi - A_{phi,k} z_k for exact ion solves,
                  because A_{phi,kj} = z_j (A_{kj,kj} - M); this form does not amplify the V-cycle error)
         z_phi = V_phi t + cc * t_phi,  cc = psi / (sum_j z_j^2 k_j) / M_lumped   (Cahouet-Chabard Schur term)
     The hierarchies are data built by the host setup and passed in by the test."""
-    Vk = pc_amg_vcycle(hier_k.levels, hier_k.coarse_inv, pre, post, cheby_degree)
-    Vp = pc_amg_vcycle(hier_p.levels, hier_p.coarse_inv, pre, post, cheby_degree)
+    Vk = pc_amg_vcycle(hier_k.levels, hier_k.coarse_inv, pre, post, cheby_degree, fused=fused)
+    Vp = pc_amg_vcycle(hier_p.levels, hier_p.coarse_inv, pre, post, cheby_degree, fused=fused)
     n = o.n_dof
     nn = o.lay.n_nodes
     nv1 = o.dim + 1

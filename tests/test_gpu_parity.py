@@ -181,7 +181,8 @@ def test_gmres_amg_iterates_match_oracle_gmres(N, kind, steps, fp32):
     assert len(h.levels) >= 2
     o = make_oracle(N, kind)
     xo, its = o.run(steps, solver="gmres", rtol=1e-9,
-                    pc=lambda P: K.pc_amg_vcycle(h.levels, h.coarse_inv, s.amg_pre, s.amg_post, s.amg_cheby_degree))
+                    pc=lambda P: K.pc_amg_vcycle(h.levels, h.coarse_inv, s.amg_pre, s.amg_post, s.amg_cheby_degree,
+                                                 fused=bool(s.backend.stats()["fused"])))
     assert its == list(s.iterations)
     x = s.backend.x.cpu().numpy()
     for f in range(4):
@@ -204,7 +205,7 @@ def test_btcc_iterates_match_oracle(N, kind, steps, fp32):
     assert len(hk.levels) >= 2 and len(hp.levels) >= 2
     o = make_oracle(N, kind)
     xo, its = o.run(steps, solver="gmres", rtol=1e-9,
-                    pc=lambda P: K.pc_btcc(o, hk, hp, s.amg_pre, s.amg_post, s.amg_cheby_degree))
+                    pc=lambda P: K.pc_btcc(o, hk, hp, s.amg_pre, s.amg_post, s.amg_cheby_degree, fused=bool(s.backend.stats()["fused"])))
     assert its == list(s.iterations)
     assert max(its) <= (6 if kind == "square" else 20)
     x = s.backend.x.cpu().numpy()
@@ -336,9 +337,9 @@ def test_dirichlet_bcs_without_mms(kind, N, pc):
     def fac(P):                       # the hierarchies are data: the ones the host setup built for the library
         if pc == "btcc":
             hk, hp = s.hierarchies
-            return K.pc_btcc(o, hk, hp, s.amg_pre, s.amg_post, s.amg_cheby_degree, bc_dofs=dofs)
+            return K.pc_btcc(o, hk, hp, s.amg_pre, s.amg_post, s.amg_cheby_degree, bc_dofs=dofs, fused=bool(s.backend.stats()["fused"]))
         h = s.hierarchy
-        return K.pc_amg_vcycle(h.levels, h.coarse_inv, s.amg_pre, s.amg_post, s.amg_cheby_degree)
+        return K.pc_amg_vcycle(h.levels, h.coarse_inv, s.amg_pre, s.amg_post, s.amg_cheby_degree, fused=bool(s.backend.stats()["fused"]))
     xo = o.run_dirichlet(2, dofs, vals, solver="gmres", pc=fac, rtol=1e-11)
     assert o.dirichlet_iterations == list(s.iterations)
     xn = s.backend.x.cpu().numpy()
