@@ -176,25 +176,28 @@ class Stepper:
 
 
 def spmv_bytes(be):
-    """Bytes one SpMV on A must move: the node-structured kernel reads the matrix values (8 B/nnz)
-    but only a 4-B neighbour index per node pair instead of a 4-B column index per entry.  Returns (node kernel, CSR)."""
+    """Bytes one SpMV on A must move: the node-structured kernel reads the matrix values (8 B per entry,
+    pair-major) and a 4-B neighbour index per node PAIR instead of a 4-B column index per entry, the pair pointer, the
+    membrane index and side of every node, a 4-B column per membrane coupling, x and y.  Returns (node kernel, CSR)."""
     n_own, n_loc = be.n_dof_owned, be.n_dof_local
+    n_gp = be.sizes[8]                                                                  # membrane vertex pairs (KNP_SZ_N_GAMMA_PAIRS)
     b_csr = 12.0 * be.nnz + 4.0 * (n_own + 1) + 8.0 * n_own + 8.0 * n_loc          # SURVEY 8(d) CSR figure
-    b_node = 8.0 * be.nnz + 4.0 * be.n_pairs + 4.0 * (n_own + 1) + 4.0 * (be.n_nodes_owned + 1) + 8.0 * n_own + 8.0 * n_loc
+    b_node = (8.0 * be.nnz + 4.0 * be.n_pairs + 4.0 * (be.n_nodes_owned + 1) + 5.0 * be.n_nodes_owned + 4.0 * 2 * n_gp
+              + 8.0 * n_own + 8.0 * n_loc)
     return b_node, b_csr
 
 
 def roofline_block(be, prof, workload, world):
     spmv_ms, spmv_n = prof["spmv"]
     b_node, b_csr = spmv_bytes(be)
-    node_kernel = os.environ.get("KNP_SPMV", "") != "csr"
-    b_alg = b_node if node_kernel else b_csr
+    node_kernel = True
+    b_alg = b_node
     if not (spmv_n > 0 and spmv_ms > 0):
         return None
     avg_s = spmv_ms * 1e-3 / spmv_n
     ach = b_alg / avg_s / 1e9
     in_cache = be.nnz * 8 < 200e6
-    roof = {"bound": "hbm", "kernel": "k_spmv_node (SpMV on A)" if node_kernel else "k_spmv<L,*,1> (CSR SpMV on A)",
+    roof = {"bound": "hbm", "kernel": "k_spmv_node (SpMV on A)",
             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
             "traffic_source": None, "bytes_per_launch": b_alg, "csr_equivalent_bytes": b_csr, "csr_equivalent_GBs": b_csr / avg_s / 1e9,
             "avg_launch_us": avg_s * 1e6, "launches": int(spmv_n), "working_set": "infinity-cache resident" if in_cache else "exceeds the infinity cache",

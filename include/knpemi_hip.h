@@ -191,9 +191,12 @@ int knp_p2p_test_allreduce(knp_ctx* ctx, int32_t plan, double* v /* device */, i
 int knp_get_sizes(const knp_ctx* ctx, int64_t* sizes /* host [KNP_SZ_COUNT] */);
 int knp_get_layout(const knp_ctx* ctx, int32_t* node_i, int32_t* node_e /* host [n_vertices] each */);
 int knp_get_csr_pattern(const knp_ctx* ctx, int32_t* rowptr, int32_t* colind /* host */);
+/* A is held pair-major on the device; these two export it as standard CSR for checkers: rows = owned DoFs,
+ * row (n,j<3) = [(nb,j),(nb,phi) for nb in the node's pairs] ++ [(cross,phi)], row (n,phi) = [(nb,0..3) ...] ++ [(cross,phi)] */
 int knp_get_csr_values(const knp_ctx* ctx, double* vals /* host [nnz] */);
 int knp_get_precond_csr(const knp_ctx* ctx, int32_t* rowptr, int32_t* colind, double* vals /* host */);
-int knp_get_device_csr(const knp_ctx* ctx, const int32_t** rowptr, const int32_t** colind, const double** vals);
+/* max |A_ij| over the locally stored entries (what the reference's null-space check scales by; device reduction) */
+int knp_matrix_max_abs(knp_ctx* ctx, double* out /* host */);
 
 /* ---- problem data ---- */
 int knp_set_params(knp_ctx* ctx, double dt, double F, double C_M, double psi, int32_t n_ions,

@@ -66,7 +66,7 @@ SIGNATURES = {
     "knp_get_csr_pattern": (C.c_int, [vp, i32p, i32p]),
     "knp_get_csr_values": (C.c_int, [vp, f64p]),
     "knp_get_precond_csr": (C.c_int, [vp, i32p, i32p, f64p]),
-    "knp_get_device_csr": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
+    "knp_matrix_max_abs": (C.c_int, [vp, f64p]),
     "knp_set_params": (C.c_int, [vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, f64p, f64p, f64p]),
     "knp_set_program": (C.c_int, [vp, C.c_int32, C.c_int32, i32p, C.c_int32, f64p]),
     "knp_set_program_constants": (C.c_int, [vp, C.c_int32, C.c_int32, f64p]),

@@ -484,12 +484,10 @@ class Backend:
         return its.value, rn.value, reason.value
 
     def matrix_max_abs(self) -> float:
-        """max |A_ij| over the locally stored entries (views the library-owned value array in place)."""
-        vals = C.c_void_p()
-        self.check(self.lib.knp_get_device_csr(self.ctx, None, None, C.byref(vals)))
-        if self.nnz == 0:
-            return 0.0
-        return float(self._view(vals.value, self.nnz).abs().max().item())
+        """max |A_ij| over the locally stored entries (device reduction over the pair-major arrays)."""
+        out = C.c_double()
+        self.check(self.lib.knp_matrix_max_abs(self.ctx, C.byref(out)))
+        return out.value
 
     def l2_norms_sq(self):
         out = (C.c_double * 2)()

@@ -41,13 +41,15 @@ struct KnpHostGraph {
     std::vector<int32_t> gcptr;                   // [n_gp+1]
     std::vector<int32_t> gc_facet;                // [n_gc]
     std::vector<int32_t> gc_lab;                  // [n_gc] la*4+lb
-    // CSR pattern of A
+    // CSR pattern of A: export only (knp_get_csr_*), built on demand by knp_build_csr_pattern -- the device never reads it
+    int64_t nnz = 0;
     std::vector<int32_t> rowptr;                  // [4*n_nodes_owned+1]
     std::vector<int32_t> colind;                  // [nnz]
     std::string error;
 };
 
 int knp_build_graph(const knp_mesh_desc* m, KnpHostGraph& g);
+int knp_build_csr_pattern(KnpHostGraph& g);
 struct knp_ctx;
 void knp_jit_build(knp_ctx* ctx);
 void knp_jit_release(knp_ctx* ctx);
@@ -171,9 +173,13 @@ struct knp_ctx {
     int32_t *d_gptr = nullptr, *d_gcol = nullptr, *d_grow = nullptr, *d_gq_i = nullptr, *d_gq_e = nullptr,
             *d_gdiag = nullptr;
     int32_t *d_gcptr = nullptr, *d_gc_facet = nullptr, *d_gc_lab = nullptr;
-    // CSR of A; P pair-major (p_vals[4*pair + field])
-    int32_t *d_rowptr = nullptr, *d_colind = nullptr;
-    double* d_vals = nullptr;
+    // A, pair-major: per same-side node pair p = (n, nb) the 10 entries of the 4x4 block, split into
+    //   a_t[4p + {0,1,2}] = A[(n,j),(nb,phi)]   a_t[4p+3] = A[(n,phi),(nb,phi)]        (depend on the previous solution)
+    //   a_c[6p + j]       = A[(n,j),(nb,j)]     a_c[6p+3+j] = A[(n,phi),(nb,j)]        (time invariant)
+    // and per membrane vertex pair s the coupling to the other side's potential, a_x[8s + 4*side + f] = A[(n_side,f),(cross,phi)]
+    // P pair-major (p_vals[4*pair + field])
+    double *d_at = nullptr, *d_ac = nullptr, *d_ax = nullptr;
+    int32_t *d_gx_i = nullptr, *d_gx_e = nullptr;
     double* d_p_vals = nullptr;
     bool have_A = false, have_P = false, have_cc = false;
     // work arrays
@@ -211,6 +217,7 @@ struct knp_ctx {
     int ns_on = 0;
     int spmv_group = 8;   // lanes per node of the node-structured SpMV (0 = generic CSR kernel)
     int pc_group = 8;     // lanes per node of the level-0 preconditioner kernels (k_pnode, k_phi_rhs)
+    int asm_group = 8;    // lanes per node of the volume assembly (one lane per node pair)
     // GMRES workspace
     int gm_restart = 0;
     double* d_V = nullptr;       // [(restart+1)*n_dof_local]

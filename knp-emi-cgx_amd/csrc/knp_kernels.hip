@@ -2,8 +2,8 @@
 // assemble-and-solve hot path.  Everything here is HBM-bandwidth bound: no MFMA.
 //
 //   K0  k_cell_means            per-cell means of the previous concentrations (feeds K[c] blocks)
-//   K1  k_assemble_pairs        gather-assembly of all volume blocks of A (or P) into CSR, one
-//                               thread per same-side node pair, atomic-free and deterministic
+//   K1  k_assemble_nodes        gather-assembly of all volume blocks of A (or P) into the pair-major arrays, one lane
+//                               per same-side node pair, atomic-free and deterministic
 //   K2  k_gamma_facets          membrane facet quadrature (rational alpha weights, mechanism programs)
 //   K2b k_gamma_pairs           gather of facet matrices into the CSR coupling entries
 //   K3  k_rhs                   mass * k_prev + membrane vectors -> b
@@ -110,74 +110,87 @@ __global__ void __launch_bounds__(NT) k_cell_means(int n_c, int nv1, const int32
 }
 
 // ------------------------------------------------------------------------------------------
-// K1: volume blocks, one thread per node pair
+// K1: volume blocks.  One G-lane group per owned node, one lane per node pair (n, nb): the lane sums the pair's cell
+// contributions K_ab(T) * cbar_T (gather, atomic-free, deterministic) and writes the pair's entries as whole 16-byte pieces
+// of the pair-major arrays -- consecutive lanes write consecutive addresses.  The self pair has no contribution list:
+// sum_b K_ab(T) = 0 on every simplex, so its weighted stiffness is minus the sum over the node's other pairs (a shuffle
+// reduction over the group) -- a quarter of the gathers and no 24-contribution straggler lane per node.
 // ------------------------------------------------------------------------------------------
-#define ASM_G 1   // lanes per node pair in K1 (4 lanes: -4 % on cube64, +6 % on square512 -- not worth a second instantiation)
-template <bool PRECOND, bool TD_ONLY, int G>   // TD_ONLY: write only the entries that depend on the previous solution; G lanes per pair
+template <bool PRECOND, bool TD_ONLY, int G>   // TD_ONLY: write only the entries that depend on the previous solution
 __global__ void __launch_bounds__(NT)
-k_assemble_pairs(int64_t n_pairs, int n_c, DevParams P, const int32_t* __restrict__ pair_row,
-                 const int32_t* __restrict__ pair_ptr, const uint8_t* __restrict__ node_side,
-                 const double* __restrict__ pair_M, const double* __restrict__ pair_K,
+k_assemble_nodes(int n_nodes, DevParams P, const int32_t* __restrict__ pair_ptr, const int32_t* __restrict__ pair_col,
+                 const uint8_t* __restrict__ node_side, const double* __restrict__ pair_M, const double* __restrict__ pair_K,
                  const int32_t* __restrict__ contrib_ptr, const int32_t* __restrict__ contrib_cell,
                  const double* __restrict__ contrib_k, const double* __restrict__ cbar,
-                 const int32_t* __restrict__ rowptr, double* __restrict__ vals) {
-    // (gathering once per unordered pair and mirroring the entries was tried: the indirection and the scattered mirror
-    // writes cost more than the halved gathers save -- 15 % slower on cube64)
-    const int64_t p_raw = ((int64_t)blockIdx.x * NT + threadIdx.x) / G;
+                 double* __restrict__ at /* P: p_vals */, double* __restrict__ ac) {
+    const int node_raw = (blockIdx.x * NT + threadIdx.x) / G;
     const int lane = threadIdx.x & (G - 1);
-    const bool live = p_raw < n_pairs;
-    const int64_t p = live ? p_raw : n_pairs - 1;     // surplus lanes shadow the last pair (uniform shuffles), they do not write
-    const int n = pair_row[p];
-    const int p0 = pair_ptr[n];
-    const int q = (int)(p - p0);
-    const int side = node_side[n];
-    double S0 = 0, S1 = 0, S2 = 0;
-    const int c1 = contrib_ptr[p + 1];
-    for (int c = contrib_ptr[p] + lane; c < c1; c += G) {
-        const int cell = contrib_cell[c];
-        const double k = contrib_k[c];
-        const double2 c01 = *reinterpret_cast<const double2*>(cbar + (size_t)4 * cell);
-        const double c2 = cbar[(size_t)4 * cell + 2];
-        S0 += k * c01.x;
-        S1 += k * c01.y;
-        S2 += k * c2;
+    const bool live = node_raw < n_nodes;
+    const int node = live ? node_raw : n_nodes - 1;    // surplus groups shadow the last node (uniform shuffles), they do not write
+    const int p0 = pair_ptr[node];
+    const int deg = pair_ptr[node + 1] - p0;
+    const int side = node_side[node];
+    const double D0 = side ? P.De[0] : P.Di[0], D1 = side ? P.De[1] : P.Di[1], D2 = side ? P.De[2] : P.Di[2];
+    const double f0 = P.dt * D0 * P.z[0] / P.psi, f1 = P.dt * D1 * P.z[1] / P.psi, f2 = P.dt * D2 * P.z[2] / P.psi;
+    auto emit = [&](int p, double S0, double S1, double S2) {
+        const double phiphi = f0 * P.z[0] * S0 + f1 * P.z[1] * S1 + f2 * P.z[2] * S2;
+        if (!PRECOND) {
+            *reinterpret_cast<double2*>(at + 4 * (size_t)p) = make_double2(f0 * S0, f1 * S1);
+            *reinterpret_cast<double2*>(at + 4 * (size_t)p + 2) = make_double2(f2 * S2, phiphi);
+            if (!TD_ONLY) {
+                const double M = pair_M[p], K = pair_K[p];
+                *reinterpret_cast<double2*>(ac + 6 * (size_t)p) = make_double2(M + P.dt * D0 * K, M + P.dt * D1 * K);              // (k,k)
+                *reinterpret_cast<double2*>(ac + 6 * (size_t)p + 2) = make_double2(M + P.dt * D2 * K, P.dt * P.z[0] * D0 * K);     // (k,k) | (phi,k)
+                *reinterpret_cast<double2*>(ac + 6 * (size_t)p + 4) = make_double2(P.dt * P.z[1] * D1 * K, P.dt * P.z[2] * D2 * K);
+            }
+        } else {
+            const double M = pair_M[p], K = pair_K[p];
+            *reinterpret_cast<double2*>(at + 4 * (size_t)p) = make_double2(M + P.dt * D0 * K, M + P.dt * D1 * K);
+            *reinterpret_cast<double2*>(at + 4 * (size_t)p + 2) = make_double2(M + P.dt * D2 * K, phiphi);
+        }
+    };
+    double T0 = 0.0, T1 = 0.0, T2 = 0.0;   // this lane's share of the sum over the node's off-diagonal pairs
+    int self_p = -1;
+    for (int q = lane; q < deg; q += G) {
+        const int p = p0 + q;
+        if (pair_col[p] == node) { self_p = p; continue; }
+        double S0 = 0.0, S1 = 0.0, S2 = 0.0;
+        const int c1 = contrib_ptr[p + 1];
+        for (int c = contrib_ptr[p]; c < c1; ++c) {
+            const int cell = contrib_cell[c];
+            const double k = contrib_k[c];
+            const double2 c01 = *reinterpret_cast<const double2*>(cbar + (size_t)4 * cell);
+            const double c2 = cbar[(size_t)4 * cell + 2];
+            S0 += k * c01.x;
+            S1 += k * c01.y;
+            S2 += k * c2;
+        }
+        if (live) emit(p, S0, S1, S2);
+        T0 += S0; T1 += S1; T2 += S2;
     }
 #pragma unroll
     for (int o = G >> 1; o > 0; o >>= 1) {
-        S0 += __shfl_xor(S0, o, G);
-        S1 += __shfl_xor(S1, o, G);
-        S2 += __shfl_xor(S2, o, G);
+        T0 += __shfl_xor(T0, o, G);
+        T1 += __shfl_xor(T1, o, G);
+        T2 += __shfl_xor(T2, o, G);
     }
-    if (!live || lane != 0) return;
-    const double S[3] = {S0, S1, S2};
-    const double M = pair_M[p], K = pair_K[p];
-    double phiphi = 0.0;
-    if (!PRECOND) {
-        const int rphi = rowptr[4 * n + 3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const double D = side ? P.De[j] : P.Di[j];
-            const double z = P.z[j];
-            const int rj = rowptr[4 * n + j];
-            if (!TD_ONLY) {
-                vals[rj + 2 * q] = M + P.dt * D * K;          // (k,k):   time invariant
-                vals[rphi + 4 * q + j] = P.dt * z * D * K;    // (phi,k): time invariant
-            }
-            vals[rj + 2 * q + 1] = P.dt * D * z / P.psi * S[j];
-            phiphi += P.dt * D * z * z / P.psi * S[j];
-        }
-        vals[rphi + 4 * q + 3] = phiphi;
-    } else {
-        // P is stored pair-major: the 4 per-field entries of a node pair are contiguous (32 B)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const double D = side ? P.De[j] : P.Di[j];
-            const double z = P.z[j];
-            vals[(int64_t)4 * p + j] = M + P.dt * D * K;
-            phiphi += P.dt * D * z * z / P.psi * S[j];
-        }
-        vals[(int64_t)4 * p + 3] = phiphi;
+    if (live && self_p >= 0) emit(self_p, -T0, -T1, -T2);
+}
+template <bool PRECOND, bool TD_ONLY>
+static void launch_assemble_nodes(knp_ctx* ctx, const DevParams& P, double* at, double* ac) {
+    const KnpHostGraph& g = ctx->g;
+    const int n = g.n_nodes_owned;
+    if (n <= 0) return;
+#define KNP_ASM(GG) hipLaunchKernelGGL((k_assemble_nodes<PRECOND, TD_ONLY, GG>), dim3(nblocks((int64_t)n * GG)), dim3(NT), 0, ctx->stream, n, P, ctx->d_pair_ptr, \
+                                       ctx->d_pair_col, ctx->d_node_side, ctx->d_pair_M, ctx->d_pair_K, ctx->d_contrib_ptr, ctx->d_contrib_cell,       \
+                                       ctx->d_contrib_k, ctx->d_cbar, at, ac)
+    switch (ctx->asm_group) {
+        case 4: KNP_ASM(4); break;
+        case 8: KNP_ASM(8); break;
+        case 16: KNP_ASM(16); break;
+        default: KNP_ASM(32); break;
     }
+#undef KNP_ASM
 }
 
 // ------------------------------------------------------------------------------------------
@@ -196,11 +209,10 @@ k_gamma_pairs(int64_t n_gp, int n_g, int dim, DevParams P, const int32_t* __rest
               const int32_t* __restrict__ gq_e, const int32_t* __restrict__ gcptr,
               const int32_t* __restrict__ gc_facet, const int32_t* __restrict__ gc_lab,
               const double* __restrict__ fmeas, const double* __restrict__ fmat,
-              const int32_t* __restrict__ pair_ptr, const int32_t* __restrict__ rowptr, double* __restrict__ vals) {
+              const int32_t* __restrict__ pair_ptr, double* __restrict__ at /* P: p_vals */, double* __restrict__ ax) {
     int64_t s = (int64_t)blockIdx.x * NT + threadIdx.x;
     if (s >= n_gp) return;
     const int A = grow[s];
-    const int r = (int)(s - gptr[A]);
     const int ni = gv_node_i[A], ne = gv_node_e[A];
     const int npk = dim * (dim + 1) / 2;
     double m[6] = {0, 0, 0, 0, 0, 0};
@@ -218,32 +230,30 @@ k_gamma_pairs(int64_t n_gp, int n_g, int dim, DevParams P, const int32_t* __rest
         }
     }
     m0 *= P.C_M / P.F;
-    const int pi0 = pair_ptr[ni], pe0 = pair_ptr[ne];
-    const int degi = pair_ptr[ni + 1] - pi0, dege = pair_ptr[ne + 1] - pe0;
-    const int qi = gq_i[s], qe = gq_e[s];
+    const size_t pi = (size_t)pair_ptr[ni] + gq_i[s], pe = (size_t)pair_ptr[ne] + gq_e[s];
     if (!PRECOND) {
+        // same-side slots: + M_Gamma[C^k] on (k,phi), + (C_M/F) M_Gamma on (phi,phi); cross slots: the negatives
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const int ri = rowptr[4 * ni + j], re = rowptr[4 * ne + j];
-            vals[ri + 2 * qi + 1] += m[j];
-            vals[ri + 2 * degi + r] = -m[j];
-            vals[re + 2 * qe + 1] += m[3 + j];
-            vals[re + 2 * dege + r] = -m[3 + j];
+            at[4 * pi + j] += m[j];
+            at[4 * pe + j] += m[3 + j];
         }
-        const int ri = rowptr[4 * ni + 3], re = rowptr[4 * ne + 3];
-        vals[ri + 4 * qi + 3] += m0;
-        vals[ri + 4 * degi + r] = -m0;
-        vals[re + 4 * qe + 3] += m0;
-        vals[re + 4 * dege + r] = -m0;
+        at[4 * pi + 3] += m0;
+        at[4 * pe + 3] += m0;
+        *reinterpret_cast<double2*>(ax + 8 * (size_t)s) = make_double2(-m[0], -m[1]);
+        *reinterpret_cast<double2*>(ax + 8 * (size_t)s + 2) = make_double2(-m[2], -m0);
+        *reinterpret_cast<double2*>(ax + 8 * (size_t)s + 4) = make_double2(-m[3], -m[4]);
+        *reinterpret_cast<double2*>(ax + 8 * (size_t)s + 6) = make_double2(-m[5], -m0);
     } else {
-        vals[(int64_t)4 * (pi0 + qi) + 3] -= m0;   // KNPEMIx_problem.py:737
-        vals[(int64_t)4 * (pe0 + qe) + 3] -= m0;   // KNPEMIx_problem.py:738
+        at[4 * pi + 3] -= m0;   // KNPEMIx_problem.py:737
+        at[4 * pe + 3] -= m0;   // KNPEMIx_problem.py:738
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// K3: right-hand side, one thread per owned node
+// K3: right-hand side, one G-lane group per owned node (lanes split the node's pairs and its membrane facets)
 // ------------------------------------------------------------------------------------------
+template <int G>
 __global__ void __launch_bounds__(NT)
 k_rhs(int n_nodes_owned, int n_g, int dim, double dt, const int32_t* __restrict__ node_vertex,
       const uint8_t* __restrict__ node_side, const int32_t* __restrict__ pair_ptr,
@@ -251,44 +261,56 @@ k_rhs(int n_nodes_owned, int n_g, int dim, double dt, const int32_t* __restrict_
       int have_src, const int32_t* __restrict__ node_gv, const int32_t* __restrict__ gdiag,
       const int32_t* __restrict__ gcptr, const int32_t* __restrict__ gc_facet,
       const int32_t* __restrict__ gc_lab, const double* __restrict__ fvec, double* __restrict__ b) {
-    const int n = blockIdx.x * NT + threadIdx.x;
-    if (n >= n_nodes_owned) return;
-    const int side = node_side[n];
-    double acc[3] = {0, 0, 0};
-    const double* k0 = side ? f.ke[0] : f.ki[0];
-    const double* k1 = side ? f.ke[1] : f.ki[1];
-    const double* k2 = side ? f.ke[2] : f.ki[2];
-    for (int p = pair_ptr[n]; p < pair_ptr[n + 1]; ++p) {
-        const int vb = node_vertex[pair_col[p]];
-        const double M = pair_M[p];
-        acc[0] += M * k0[vb];
-        acc[1] += M * k1[vb];
-        acc[2] += M * k2[vb];
-        if (have_src) {
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const double* s = side ? src.ke[j] : src.ki[j];
-                if (s) acc[j] += dt * M * s[vb];
+    const int n = (blockIdx.x * NT + threadIdx.x) / G;
+    const int lane = threadIdx.x & (G - 1);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, ap = 0.0;
+    if (n < n_nodes_owned) {
+        const int side = node_side[n];
+        const double* k0 = side ? f.ke[0] : f.ki[0];
+        const double* k1 = side ? f.ke[1] : f.ki[1];
+        const double* k2 = side ? f.ke[2] : f.ki[2];
+        const int pe = pair_ptr[n + 1];
+        for (int p = pair_ptr[n] + lane; p < pe; p += G) {
+            const int vb = node_vertex[pair_col[p]];
+            const double M = pair_M[p];
+            a0 += M * k0[vb];
+            a1 += M * k1[vb];
+            a2 += M * k2[vb];
+            if (have_src) {
+                const double* s0 = side ? src.ke[0] : src.ki[0];
+                const double* s1 = side ? src.ke[1] : src.ki[1];
+                const double* s2 = side ? src.ke[2] : src.ki[2];
+                if (s0) a0 += dt * M * s0[vb];
+                if (s1) a1 += dt * M * s1[vb];
+                if (s2) a2 += dt * M * s2[vb];
+            }
+        }
+        const int A = node_gv[n];
+        if (A >= 0) {
+            const int s = gdiag[A];
+            const double sg = side ? 1.0 : -1.0;
+            const int off = side ? 3 : 0;
+            for (int c = gcptr[s] + lane; c < gcptr[s + 1]; c += G) {
+                const int fct = gc_facet[c];
+                const int la = gc_lab[c] >> 2;
+                a0 += sg * fvec[((size_t)(off + 0) * dim + la) * n_g + fct];
+                a1 += sg * fvec[((size_t)(off + 1) * dim + la) * n_g + fct];
+                a2 += sg * fvec[((size_t)(off + 2) * dim + la) * n_g + fct];
+                ap += sg * fvec[((size_t)6 * dim + la) * n_g + fct];
             }
         }
     }
-    double accp = 0.0;
-    const int A = node_gv[n];
-    if (A >= 0) {
-        const int s = gdiag[A];
-        const double sg = side ? 1.0 : -1.0;
-        for (int c = gcptr[s]; c < gcptr[s + 1]; ++c) {
-            const int fct = gc_facet[c];
-            const int la = gc_lab[c] >> 2;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) acc[j] += sg * fvec[((size_t)((side ? 3 : 0) + j) * dim + la) * n_g + fct];
-            accp += sg * fvec[((size_t)6 * dim + la) * n_g + fct];
-        }
+    for (int o = G >> 1; o > 0; o >>= 1) {
+        a0 += __shfl_xor(a0, o, G);
+        a1 += __shfl_xor(a1, o, G);
+        a2 += __shfl_xor(a2, o, G);
+        ap += __shfl_xor(ap, o, G);
     }
-    b[(size_t)4 * n + 0] = acc[0];
-    b[(size_t)4 * n + 1] = acc[1];
-    b[(size_t)4 * n + 2] = acc[2];
-    b[(size_t)4 * n + 3] = accp;
+    if (lane == 0 && n < n_nodes_owned) {
+        *reinterpret_cast<double2*>(b + (size_t)4 * n) = make_double2(a0, a1);
+        *reinterpret_cast<double2*>(b + (size_t)4 * n + 2) = make_double2(a2, ap);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -317,45 +339,55 @@ k_spmv(int n_rows, const int32_t* __restrict__ rp, const int32_t* __restrict__ c
 
 
 // ------------------------------------------------------------------------------------------
-// K4n: node-structured SpMV on the system matrix.  Same CSR value array, but one G-lane group per NODE
-// (its 4 rows are one contiguous chunk) and the column indices of the volume part are reconstructed from the
-// node graph (4 B per node pair instead of 40 B of colind): 16-byte loads of the (kk,kphi) pairs, of the
-// 4 phi-row entries and of the neighbour's 4 unknowns.  Only the membrane cross columns read colind.
+// K4n: SpMV on the system matrix, one G-lane group per NODE (its 4 rows).  Per node pair the lane reads the pair's 10
+// entries as five 16-byte loads from two contiguous streams (a_c: 48 B, a_t: 32 B per pair), the neighbour index (4 B) and
+// the neighbour's 4 unknowns (two 16-byte loads): no column index per entry, no row pointer.  Membrane nodes add the
+// coupling to the other side's potentials (a_x, 32 B + a 4-byte column per membrane neighbour).
+// `nodes` (optional) lists the nodes to process: interior / boundary split of the multi-GPU path.
 // ------------------------------------------------------------------------------------------
 template <int G, int MODE>
 __global__ void __launch_bounds__(NT)
-k_spmv_node(int n_nodes, const int32_t* __restrict__ pair_ptr, const int32_t* __restrict__ pair_col,
-            const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind, const double* __restrict__ vals,
+k_spmv_node(int n_list, const int32_t* __restrict__ nodes, const int32_t* __restrict__ pair_ptr, const int32_t* __restrict__ pair_col,
+            const double* __restrict__ ac, const double* __restrict__ at, const int32_t* __restrict__ node_gv,
+            const uint8_t* __restrict__ node_side, const int32_t* __restrict__ gptr, const int32_t* __restrict__ gx_i,
+            const int32_t* __restrict__ gx_e, const double* __restrict__ ax,
             const double* __restrict__ x, const double* __restrict__ b, double* __restrict__ y) {
-    const int node = (blockIdx.x * NT + threadIdx.x) / G;
+    const int i = (blockIdx.x * NT + threadIdx.x) / G;
     const int lane = threadIdx.x & (G - 1);
     double y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
-    if (node < n_nodes) {
+    int node = 0;
+    if (i < n_list) {
+        node = nodes ? nodes[i] : i;
         const int p0 = pair_ptr[node];
-        const int deg = pair_ptr[node + 1] - p0;
-        const int4 rr = *reinterpret_cast<const int4*>(rowptr + 4 * (size_t)node);
-        const int r0 = rr.x, r1 = rr.y, r2 = rr.z, r3 = rr.w;
-        const int xp = (r1 - r0) - 2 * deg;
-        for (int q = lane; q < deg; q += G) {
-            const int nb = pair_col[p0 + q];
+        const int p1 = pair_ptr[node + 1];
+        for (int p = p0 + lane; p < p1; p += G) {
+            const int nb = pair_col[p];
             const double2 xa = *reinterpret_cast<const double2*>(x + 4 * (size_t)nb);
             const double2 xb = *reinterpret_cast<const double2*>(x + 4 * (size_t)nb + 2);
-            const double2 a0 = *reinterpret_cast<const double2*>(vals + r0 + 2 * q);
-            const double2 a1 = *reinterpret_cast<const double2*>(vals + r1 + 2 * q);
-            const double2 a2 = *reinterpret_cast<const double2*>(vals + r2 + 2 * q);
-            const double2 f0 = *reinterpret_cast<const double2*>(vals + r3 + 4 * q);
-            const double2 f1 = *reinterpret_cast<const double2*>(vals + r3 + 4 * q + 2);
-            y0 += a0.x * xa.x + a0.y * xb.y;
-            y1 += a1.x * xa.y + a1.y * xb.y;
-            y2 += a2.x * xb.x + a2.y * xb.y;
-            y3 += f0.x * xa.x + f0.y * xa.y + f1.x * xb.x + f1.y * xb.y;
+            const double2 c0 = *reinterpret_cast<const double2*>(ac + 6 * (size_t)p);        // kk0 kk1
+            const double2 c1 = *reinterpret_cast<const double2*>(ac + 6 * (size_t)p + 2);    // kk2 phik0
+            const double2 c2 = *reinterpret_cast<const double2*>(ac + 6 * (size_t)p + 4);    // phik1 phik2
+            const double2 t0 = *reinterpret_cast<const double2*>(at + 4 * (size_t)p);        // kphi0 kphi1
+            const double2 t1 = *reinterpret_cast<const double2*>(at + 4 * (size_t)p + 2);    // kphi2 phiphi
+            y0 += c0.x * xa.x + t0.x * xb.y;
+            y1 += c0.y * xa.y + t0.y * xb.y;
+            y2 += c1.x * xb.x + t1.x * xb.y;
+            y3 += c1.y * xa.x + c2.x * xa.y + c2.y * xb.x + t1.y * xb.y;
         }
-        for (int r = lane; r < xp; r += G) {
-            const double xv = x[colind[r0 + 2 * deg + r]];
-            y0 += vals[r0 + 2 * deg + r] * xv;
-            y1 += vals[r1 + 2 * deg + r] * xv;
-            y2 += vals[r2 + 2 * deg + r] * xv;
-            y3 += vals[r3 + 4 * deg + r] * xv;
+        const int A = node_gv[node];
+        if (A >= 0) {
+            const int sd = node_side[node];
+            const int32_t* __restrict__ gx = sd ? gx_e : gx_i;
+            const int s1 = gptr[A + 1];
+            for (int s = gptr[A] + lane; s < s1; s += G) {
+                const double xv = x[4 * (size_t)gx[s] + 3];
+                const double2 v0 = *reinterpret_cast<const double2*>(ax + 8 * (size_t)s + 4 * sd);
+                const double2 v1 = *reinterpret_cast<const double2*>(ax + 8 * (size_t)s + 4 * sd + 2);
+                y0 += v0.x * xv;
+                y1 += v0.y * xv;
+                y2 += v1.x * xv;
+                y3 += v1.y * xv;
+            }
         }
     }
 #pragma unroll
@@ -365,7 +397,7 @@ k_spmv_node(int n_nodes, const int32_t* __restrict__ pair_ptr, const int32_t* __
         y2 += __shfl_xor(y2, o, G);
         y3 += __shfl_xor(y3, o, G);
     }
-    if (lane == 0 && node < n_nodes) {
+    if (lane == 0 && i < n_list) {
         double2 o0, o1;
         if (MODE) {
             const double2 b0 = *reinterpret_cast<const double2*>(b + 4 * (size_t)node);
@@ -383,14 +415,14 @@ k_spmv_node(int n_nodes, const int32_t* __restrict__ pair_ptr, const int32_t* __
 // ev_a / ev_b (optional): events bound to the kernel's own begin / end (hipExtLaunchKernelGGL), so that their elapsed time
 // is the kernel duration a profiler reports, without the gap between an event record and the launch
 template <int MODE>
-static void launch_spmv_node(hipStream_t st, int G, int n_nodes, const int32_t* pp, const int32_t* pc, const int32_t* rp,
-                             const int32_t* ci, const double* v, const double* x, const double* b, double* y,
+static void launch_spmv_node(knp_ctx* ctx, int n_list, const int32_t* nodes, const double* x, const double* b, double* y,
                              hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr) {
-    if (n_nodes <= 0) return;
-#define KNP_SPMV_NODE(GG)                                                                                                          \
-    hipExtLaunchKernelGGL((k_spmv_node<GG, MODE>), dim3(nblocks((int64_t)n_nodes * GG)), dim3(NT), 0, st, ev_a, ev_b, 0, n_nodes, pp, \
-                          pc, rp, ci, v, x, b, y)
-    switch (G) {
+    if (n_list <= 0) return;
+#define KNP_SPMV_NODE(GG)                                                                                                              \
+    hipExtLaunchKernelGGL((k_spmv_node<GG, MODE>), dim3(nblocks((int64_t)n_list * GG)), dim3(NT), 0, ctx->stream, ev_a, ev_b, 0, n_list, nodes, \
+                          ctx->d_pair_ptr, ctx->d_pair_col, ctx->d_ac, ctx->d_at, ctx->d_node_gv, ctx->d_node_side, ctx->d_gptr, ctx->d_gx_i,     \
+                          ctx->d_gx_e, ctx->d_ax, x, b, y)
+    switch (ctx->spmv_group) {
         case 4: KNP_SPMV_NODE(4); break;
         case 8: KNP_SPMV_NODE(8); break;
         case 16: KNP_SPMV_NODE(16); break;
@@ -1012,17 +1044,25 @@ k_defl_add(int n_nodes, int m, const int32_t* __restrict__ node_mode, const doub
 // lifts the right-hand side; the solution is the same.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(NT)
-k_dirichlet_rows_A(int n_bc, const int32_t* __restrict__ bc_dofs, const int32_t* __restrict__ rowptr,
-                   const int32_t* __restrict__ colind, double* __restrict__ vals) {
+k_dirichlet_rows_A(int n_bc, const int32_t* __restrict__ bc_dofs, const int32_t* __restrict__ pair_ptr,
+                   const int32_t* __restrict__ pair_col, const int32_t* __restrict__ node_gv, const uint8_t* __restrict__ node_side,
+                   const int32_t* __restrict__ gptr, double* __restrict__ ac, double* __restrict__ at, double* __restrict__ ax) {
     const int i = blockIdx.x * NT + threadIdx.x;
     if (i >= n_bc) return;
-    const int row = bc_dofs[i];
-    bool done = false;
-    for (int k = rowptr[row]; k < rowptr[row + 1]; ++k) {
-        const bool diag = !done && colind[k] == row;
-        vals[k] = diag ? 1.0 : 0.0;
-        done = done || diag;
+    const int row = bc_dofs[i], node = row >> 2, f = row & 3;
+    for (int p = pair_ptr[node]; p < pair_ptr[node + 1]; ++p) {
+        const double diag = pair_col[p] == node ? 1.0 : 0.0;
+        if (f < 3) {
+            ac[6 * (size_t)p + f] = diag;
+            at[4 * (size_t)p + f] = 0.0;
+        } else {
+            ac[6 * (size_t)p + 3] = 0.0; ac[6 * (size_t)p + 4] = 0.0; ac[6 * (size_t)p + 5] = 0.0;
+            at[4 * (size_t)p + 3] = diag;
+        }
     }
+    const int A = node_gv[node];
+    if (A >= 0)
+        for (int s = gptr[A]; s < gptr[A + 1]; ++s) ax[8 * (size_t)s + 4 * node_side[node] + f] = 0.0;
 }
 __global__ void __launch_bounds__(NT)
 k_dirichlet_rows_P(int n_bc, const int32_t* __restrict__ bc_dofs, const int32_t* __restrict__ pair_ptr,
@@ -1039,31 +1079,29 @@ k_dirichlet_rows_P(int n_bc, const int32_t* __restrict__ bc_dofs, const int32_t*
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(NT)
 k_vbj_extract(int n_nodes_owned, const int32_t* __restrict__ pair_ptr, const int32_t* __restrict__ pair_col,
-              const int32_t* __restrict__ rowptr, const double* __restrict__ vals,
-              const int32_t* __restrict__ node_gv, const int32_t* __restrict__ gptr,
+              const double* __restrict__ ac, const double* __restrict__ at, const double* __restrict__ ax,
+              const int32_t* __restrict__ node_gv, const uint8_t* __restrict__ node_side,
               const int32_t* __restrict__ gdiag, double* __restrict__ blk) {
     const int n = blockIdx.x * NT + threadIdx.x;
     if (n >= n_nodes_owned) return;
     const int p0 = pair_ptr[n], deg = pair_ptr[n + 1] - p0;
-    int qs = 0;
+    size_t ps = p0;
     for (int q = 0; q < deg; ++q)
-        if (pair_col[p0 + q] == n) { qs = q; break; }
+        if (pair_col[p0 + q] == n) { ps = (size_t)p0 + q; break; }
     double* o = blk + (size_t)16 * n;
-    const int rphi = rowptr[4 * n + 3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const int rj = rowptr[4 * n + j];
-        o[j] = vals[rj + 2 * qs];
-        o[3 + j] = vals[rj + 2 * qs + 1];
-        o[6 + j] = vals[rphi + 4 * qs + j];
+        o[j] = ac[6 * ps + j];
+        o[3 + j] = at[4 * ps + j];
+        o[6 + j] = ac[6 * ps + 3 + j];
     }
-    o[9] = vals[rphi + 4 * qs + 3];
+    o[9] = at[4 * ps + 3];
     const int A = node_gv[n];
     if (A >= 0) {
-        const int rs = gdiag[A] - gptr[A];
+        const size_t s = (size_t)gdiag[A];
+        const int sd = node_side[n];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) o[10 + j] = vals[rowptr[4 * n + j] + 2 * deg + rs];
-        o[13] = vals[rphi + 4 * deg + rs];
+        for (int j = 0; j < 4; ++j) o[10 + j] = ax[8 * s + 4 * sd + j];
     } else {
         o[10] = o[11] = o[12] = o[13] = 0.0;
     }
@@ -1280,6 +1318,22 @@ k_unpack(int n_v, const int32_t* __restrict__ node_i, const int32_t* __restrict_
     f.phi_m[v] = pi - pe;
 }
 
+// partial[blk] = max |v| over the block's share
+__global__ void __launch_bounds__(NT) k_absmax(int64_t n, const double* __restrict__ v, double* __restrict__ partial) {
+    __shared__ double sm[NT / 64];
+    double a = 0.0;
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < n; e += (int64_t)gridDim.x * NT) a = fmax(a, fabs(v[e]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a = fmax(a, __shfl_xor(a, o, 64));
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if (l == 0) sm[w] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < NT / 64; ++k) a = fmax(a, sm[k]);
+        partial[blockIdx.x] = a;
+    }
+}
+
 // L2 norms: partial[blk] (intra), partial[RED_BLOCKS + blk] (extra)
 template <int DIM>
 __global__ void __launch_bounds__(NT)
@@ -1420,7 +1474,7 @@ int knp_create(knp_ctx** out, const knp_mesh_desc* mesh) {
     ctx->n_contrib = (int64_t)g.contrib_cell.size();
     ctx->n_gp = (int64_t)g.gcol.size();
     ctx->n_gc = (int64_t)g.gc_facet.size();
-    ctx->nnz = (int64_t)g.colind.size();
+    ctx->nnz = g.nnz;
     ctx->n_dof_owned = 4 * g.n_nodes_owned;
     ctx->n_dof_local = 4 * g.n_nodes;
     const int dim = g.dim, nv1 = g.nv1;
@@ -1458,10 +1512,14 @@ int knp_create(knp_ctx** out, const knp_mesh_desc* mesh) {
     KCHK(dev_upload(ctx, &ctx->d_gcptr, g.gcptr));
     KCHK(dev_upload(ctx, &ctx->d_gc_facet, g.gc_facet));
     KCHK(dev_upload(ctx, &ctx->d_gc_lab, g.gc_lab));
-    KCHK(dev_upload(ctx, &ctx->d_rowptr, g.rowptr));
-    KCHK(dev_upload(ctx, &ctx->d_colind, g.colind));
-    HIPCHK(hipMalloc((void**)&ctx->d_vals, std::max<int64_t>(ctx->nnz, 1) * sizeof(double)));
-    HIPCHK(hipMemset(ctx->d_vals, 0, std::max<int64_t>(ctx->nnz, 1) * sizeof(double)));
+    KCHK(dev_upload(ctx, &ctx->d_gx_i, g.gx_i));
+    KCHK(dev_upload(ctx, &ctx->d_gx_e, g.gx_e));
+    HIPCHK(hipMalloc((void**)&ctx->d_at, std::max<int64_t>(4 * ctx->n_pairs, 2) * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&ctx->d_ac, std::max<int64_t>(6 * ctx->n_pairs, 2) * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&ctx->d_ax, std::max<int64_t>(8 * ctx->n_gp, 2) * sizeof(double)));
+    HIPCHK(hipMemset(ctx->d_at, 0, std::max<int64_t>(4 * ctx->n_pairs, 2) * sizeof(double)));
+    HIPCHK(hipMemset(ctx->d_ac, 0, std::max<int64_t>(6 * ctx->n_pairs, 2) * sizeof(double)));
+    HIPCHK(hipMemset(ctx->d_ax, 0, std::max<int64_t>(8 * ctx->n_gp, 2) * sizeof(double)));
     {   // lumped mass per owned node (row sums of the P1 mass matrix): diagonal Schur term of the potential
         std::vector<double> ML(std::max(g.n_nodes_owned, 1), 0.0);
         for (int n = 0; n < g.n_nodes_owned; ++n)
@@ -1497,10 +1555,12 @@ int knp_create(knp_ctx** out, const knp_mesh_desc* mesh) {
         const char* ef = getenv("KNP_ASM_FULL");
         ctx->asm_full = (ef && atoi(ef) > 0) ? 1 : 0;
         const char* e = getenv("KNP_SPMV");
-        if (e && !strcmp(e, "csr")) ctx->spmv_group = 0;   // generic CSR kernel (k_spmv<L,*,1>)
-        else if (e && atoi(e) > 0) ctx->spmv_group = atoi(e);
+        if (e && atoi(e) > 0) ctx->spmv_group = atoi(e);
+        ctx->asm_group = ctx->spmv_group;
+        const char* ea = getenv("KNP_ASM_GROUP");
+        if (ea && atoi(ea) > 0) ctx->asm_group = atoi(ea);
         // the level-0 preconditioner kernels move half the bytes per node pair (fp32 P, no cross block): fewer lanes per node
-        ctx->pc_group = std::max(4, (ctx->spmv_group > 0 ? ctx->spmv_group : 16) / 2);
+        ctx->pc_group = std::max(4, ctx->spmv_group / 2);
         const char* ep = getenv("KNP_PC_GROUP");
         if (ep && atoi(ep) > 0) ctx->pc_group = atoi(ep);
     }
@@ -1526,7 +1586,7 @@ int knp_destroy(knp_ctx* ctx) {
     dev_free(ctx->d_gv_vertex); dev_free(ctx->d_gv_node_i); dev_free(ctx->d_gv_node_e); dev_free(ctx->d_node_gv);
     dev_free(ctx->d_gptr); dev_free(ctx->d_gcol); dev_free(ctx->d_grow); dev_free(ctx->d_gq_i); dev_free(ctx->d_gq_e);
     dev_free(ctx->d_gdiag); dev_free(ctx->d_gcptr); dev_free(ctx->d_gc_facet); dev_free(ctx->d_gc_lab);
-    dev_free(ctx->d_rowptr); dev_free(ctx->d_colind); dev_free(ctx->d_vals);
+    dev_free(ctx->d_at); dev_free(ctx->d_ac); dev_free(ctx->d_ax); dev_free(ctx->d_gx_i); dev_free(ctx->d_gx_e);
     dev_free(ctx->d_p_vals);
     dev_free(ctx->d_cbar); dev_free(ctx->d_fmat); dev_free(ctx->d_fvec);
     dev_free(ctx->d_partial); dev_free(ctx->d_red); dev_free(ctx->d_y); dev_free(ctx->d_vbj);
@@ -1577,17 +1637,41 @@ int knp_get_layout(const knp_ctx* ctx, int32_t* ni, int32_t* ne) {
     std::memcpy(ne, ctx->g.node_e.data(), ctx->g.node_e.size() * sizeof(int32_t));
     return KNP_OK;
 }
-int knp_get_csr_pattern(const knp_ctx* ctx, int32_t* rp, int32_t* ci) {
+int knp_get_csr_pattern(const knp_ctx* cctx, int32_t* rp, int32_t* ci) {
+    knp_ctx* ctx = const_cast<knp_ctx*>(cctx);
     if (!ctx || !rp || !ci) return KNP_E_ARG;
+    KCHK(knp_build_csr_pattern(ctx->g));
     std::memcpy(rp, ctx->g.rowptr.data(), ctx->g.rowptr.size() * sizeof(int32_t));
     std::memcpy(ci, ctx->g.colind.data(), ctx->g.colind.size() * sizeof(int32_t));
     return KNP_OK;
 }
+// A in the CSR order of knp_get_csr_pattern, gathered on the host from the pair-major device arrays (parity hook, not a hot path)
 int knp_get_csr_values(const knp_ctx* cctx, double* vals) {
     knp_ctx* ctx = const_cast<knp_ctx*>(cctx);
     if (!ctx || !vals) return KNP_E_ARG;
+    KCHK(knp_build_csr_pattern(ctx->g));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    HIPCHK(hipMemcpy(vals, ctx->d_vals, ctx->nnz * sizeof(double), hipMemcpyDeviceToHost));
+    const KnpHostGraph& g = ctx->g;
+    std::vector<double> at((size_t)4 * ctx->n_pairs), ac((size_t)6 * ctx->n_pairs), ax((size_t)8 * ctx->n_gp);
+    if (!at.empty()) HIPCHK(hipMemcpy(at.data(), ctx->d_at, at.size() * sizeof(double), hipMemcpyDeviceToHost));
+    if (!ac.empty()) HIPCHK(hipMemcpy(ac.data(), ctx->d_ac, ac.size() * sizeof(double), hipMemcpyDeviceToHost));
+    if (!ax.empty()) HIPCHK(hipMemcpy(ax.data(), ctx->d_ax, ax.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int n = 0; n < g.n_nodes_owned; ++n) {
+        const int p0 = g.pair_ptr[n], deg = g.pair_ptr[n + 1] - p0;
+        const int A = g.node_gv[n], sd = g.node_side[n];
+        const int s0 = A >= 0 ? g.gptr[A] : 0, x = A >= 0 ? g.gptr[A + 1] - g.gptr[A] : 0;
+        for (int f = 0; f < 3; ++f) {
+            double* v = vals + g.rowptr[(size_t)4 * n + f];
+            for (int q = 0; q < deg; ++q) { v[2 * q] = ac[(size_t)6 * (p0 + q) + f]; v[2 * q + 1] = at[(size_t)4 * (p0 + q) + f]; }
+            for (int r = 0; r < x; ++r) v[2 * deg + r] = ax[(size_t)8 * (s0 + r) + 4 * sd + f];
+        }
+        double* v = vals + g.rowptr[(size_t)4 * n + 3];
+        for (int q = 0; q < deg; ++q) {
+            for (int f = 0; f < 3; ++f) v[4 * q + f] = ac[(size_t)6 * (p0 + q) + 3 + f];
+            v[4 * q + 3] = at[(size_t)4 * (p0 + q) + 3];
+        }
+        for (int r = 0; r < x; ++r) v[4 * deg + r] = ax[(size_t)8 * (s0 + r) + 4 * sd + 3];
+    }
     return KNP_OK;
 }
 int knp_get_precond_csr(const knp_ctx* cctx, int32_t* rp, int32_t* ci, double* vals) {
@@ -1610,11 +1694,23 @@ int knp_get_precond_csr(const knp_ctx* cctx, int32_t* rp, int32_t* ci, double* v
     rp[(size_t)4 * g.n_nodes_owned] = (int32_t)(4 * ctx->n_pairs);
     return KNP_OK;
 }
-int knp_get_device_csr(const knp_ctx* ctx, const int32_t** rp, const int32_t** ci, const double** v) {
-    if (!ctx) return KNP_E_ARG;
-    if (rp) *rp = ctx->d_rowptr;
-    if (ci) *ci = ctx->d_colind;
-    if (v) *v = ctx->d_vals;
+int knp_matrix_max_abs(knp_ctx* ctx, double* out) {
+    CHECK_CTX(ctx);
+    if (!out) return KNP_E_ARG;
+    if (!ctx->have_A) { ctx->err = "matrix not assembled"; return KNP_E_STATE; }
+    const double* arr[3] = {ctx->d_at, ctx->d_ac, ctx->d_ax};
+    const int64_t len[3] = {4 * ctx->n_pairs, 6 * ctx->n_pairs, 8 * ctx->n_gp};
+    std::vector<double> h(3 * RED_BLOCKS, 0.0);
+    for (int k = 0; k < 3; ++k)
+        if (len[k] > 0) hipLaunchKernelGGL(k_absmax, dim3(RED_BLOCKS), dim3(NT), 0, ctx->stream, len[k], arr[k], ctx->d_partial + (size_t)k * RED_BLOCKS);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(h.data(), ctx->d_partial, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+    double m = 0.0;
+    for (int k = 0; k < 3; ++k)
+        if (len[k] > 0)
+            for (int b = 0; b < RED_BLOCKS; ++b) m = std::max(m, h[(size_t)k * RED_BLOCKS + b]);
+    *out = m;
     return KNP_OK;
 }
 
@@ -1776,16 +1872,8 @@ int knp_assemble_matrix(knp_ctx* ctx, const knp_fields* fields) {
     // assembly only the K[k_prev]-type and membrane entries are rewritten, unless KNP_ASM_FULL=1 asks for the
     // reference's behaviour (A.zeroEntries() + full re-assembly, KNPEMIx_solver.py:110-115).
     const bool td_only = ctx->have_A && !ctx->asm_full && ctx->asm_dt == ctx->dt;
-    if (ctx->n_pairs) {
-        if (td_only)
-            hipLaunchKernelGGL((k_assemble_pairs<false, true, ASM_G>), dim3(nblocks(ctx->n_pairs * ASM_G)), dim3(NT), 0, ctx->stream, ctx->n_pairs,
-                               g.n_c, P, ctx->d_pair_row, ctx->d_pair_ptr, ctx->d_node_side, ctx->d_pair_M, ctx->d_pair_K,
-                               ctx->d_contrib_ptr, ctx->d_contrib_cell, ctx->d_contrib_k, ctx->d_cbar, ctx->d_rowptr, ctx->d_vals);
-        else
-            hipLaunchKernelGGL((k_assemble_pairs<false, false, ASM_G>), dim3(nblocks(ctx->n_pairs * ASM_G)), dim3(NT), 0, ctx->stream, ctx->n_pairs,
-                               g.n_c, P, ctx->d_pair_row, ctx->d_pair_ptr, ctx->d_node_side, ctx->d_pair_M, ctx->d_pair_K,
-                               ctx->d_contrib_ptr, ctx->d_contrib_cell, ctx->d_contrib_k, ctx->d_cbar, ctx->d_rowptr, ctx->d_vals);
-    }
+    if (td_only) launch_assemble_nodes<false, true>(ctx, P, ctx->d_at, ctx->d_ac);
+    else launch_assemble_nodes<false, false>(ctx, P, ctx->d_at, ctx->d_ac);
     ctx->asm_dt = ctx->dt;
     if (g.n_g > 0) {
         if (g.dim == 2)
@@ -1802,11 +1890,11 @@ int knp_assemble_matrix(knp_ctx* ctx, const knp_fields* fields) {
             hipLaunchKernelGGL((k_gamma_pairs<false>), dim3(nblocks(ctx->n_gp)), dim3(NT), 0, ctx->stream, ctx->n_gp, g.n_g, g.dim, P,
                                ctx->d_grow, ctx->d_gptr, ctx->d_gv_node_i, ctx->d_gv_node_e, ctx->d_gq_i, ctx->d_gq_e,
                                ctx->d_gcptr, ctx->d_gc_facet, ctx->d_gc_lab, ctx->d_fmeas, ctx->d_fmat, ctx->d_pair_ptr,
-                               ctx->d_rowptr, ctx->d_vals);
+                               ctx->d_at, ctx->d_ax);
     }
     if (ctx->n_bc > 0)
-        hipLaunchKernelGGL(k_dirichlet_rows_A, dim3(nblocks(ctx->n_bc)), dim3(NT), 0, ctx->stream, ctx->n_bc, ctx->d_bc_dofs, ctx->d_rowptr,
-                           ctx->d_colind, ctx->d_vals);
+        hipLaunchKernelGGL(k_dirichlet_rows_A, dim3(nblocks(ctx->n_bc)), dim3(NT), 0, ctx->stream, ctx->n_bc, ctx->d_bc_dofs, ctx->d_pair_ptr,
+                           ctx->d_pair_col, ctx->d_node_gv, ctx->d_node_side, ctx->d_gptr, ctx->d_ac, ctx->d_at, ctx->d_ax);
     // The Schur diagonal depends on the fields only.  knp_assemble_rhs of the same step has already written it; while a
     // side-stream preconditioner application (knp_gmres_prepare) is in flight it READS d_cc, so it must not be rewritten here.
     if (!ctx->prep_b) launch_schur_diag(ctx, f);
@@ -1814,7 +1902,7 @@ int knp_assemble_matrix(knp_ctx* ctx, const knp_fields* fields) {
     ctx->have_A = true;
     if (ctx->pc_kind == KNP_PC_VBJACOBI) {
         hipLaunchKernelGGL(k_vbj_extract, dim3(nblocks(g.n_nodes_owned)), dim3(NT), 0, ctx->stream, g.n_nodes_owned,
-                           ctx->d_pair_ptr, ctx->d_pair_col, ctx->d_rowptr, ctx->d_vals, ctx->d_node_gv, ctx->d_gptr,
+                           ctx->d_pair_ptr, ctx->d_pair_col, ctx->d_ac, ctx->d_at, ctx->d_ax, ctx->d_node_gv, ctx->d_node_side,
                            ctx->d_gdiag, ctx->d_vbj);
         HIPCHK(hipGetLastError());
     }
@@ -1831,15 +1919,12 @@ int knp_assemble_precond(knp_ctx* ctx, const knp_fields* fields) {
     ProfScope ps(ctx, 3);
     hipLaunchKernelGGL(k_cell_means, dim3(nblocks(g.n_c)), dim3(NT), 0, ctx->stream, g.n_c, g.nv1, ctx->d_cells,
                        ctx->d_cell_side, f, ctx->d_cbar);
-    if (ctx->n_pairs)
-        hipLaunchKernelGGL((k_assemble_pairs<true, false, ASM_G>), dim3(nblocks(ctx->n_pairs * ASM_G)), dim3(NT), 0, ctx->stream, ctx->n_pairs,
-                           g.n_c, P, ctx->d_pair_row, ctx->d_pair_ptr, ctx->d_node_side, ctx->d_pair_M, ctx->d_pair_K,
-                           ctx->d_contrib_ptr, ctx->d_contrib_cell, ctx->d_contrib_k, ctx->d_cbar, ctx->d_rowptr, ctx->d_p_vals);
+    launch_assemble_nodes<true, false>(ctx, P, ctx->d_p_vals, nullptr);
     if (g.n_g > 0 && ctx->n_gp)
         hipLaunchKernelGGL((k_gamma_pairs<true>), dim3(nblocks(ctx->n_gp)), dim3(NT), 0, ctx->stream, ctx->n_gp, g.n_g, g.dim, P,
                            ctx->d_grow, ctx->d_gptr, ctx->d_gv_node_i, ctx->d_gv_node_e, ctx->d_gq_i, ctx->d_gq_e,
                            ctx->d_gcptr, ctx->d_gc_facet, ctx->d_gc_lab, ctx->d_fmeas, ctx->d_fmat, ctx->d_pair_ptr,
-                           ctx->d_rowptr, ctx->d_p_vals);
+                           ctx->d_p_vals, nullptr);
     if (ctx->n_bc > 0)
         hipLaunchKernelGGL(k_dirichlet_rows_P, dim3(nblocks(ctx->n_bc)), dim3(NT), 0, ctx->stream, ctx->n_bc, ctx->d_bc_dofs, ctx->d_pair_ptr,
                            ctx->d_pair_col, ctx->d_p_vals);
@@ -1908,10 +1993,18 @@ int knp_assemble_rhs(knp_ctx* ctx, const knp_fields* fields, double* b) {
     for (int j = 0; j < 3; ++j) { src.ki[j] = ctx->src_i[j]; src.ke[j] = ctx->src_e[j]; }
     src.phim = nullptr;
     for (int k = 0; k < KNP_MAX_AUX; ++k) src.aux[k] = nullptr;
-    hipLaunchKernelGGL(k_rhs, dim3(nblocks(g.n_nodes_owned)), dim3(NT), 0, ctx->stream, g.n_nodes_owned, g.n_g, g.dim, ctx->dt,
-                       ctx->d_node_vertex, ctx->d_node_side, ctx->d_pair_ptr, ctx->d_pair_col, ctx->d_pair_M, f, src,
-                       ctx->have_sources ? 1 : 0, ctx->d_node_gv, ctx->d_gdiag, ctx->d_gcptr, ctx->d_gc_facet, ctx->d_gc_lab,
-                       ctx->d_fvec, b);
+#define KNP_RHS(GG) hipLaunchKernelGGL((k_rhs<GG>), dim3(nblocks((int64_t)g.n_nodes_owned * GG)), dim3(NT), 0, ctx->stream, g.n_nodes_owned, g.n_g, g.dim, ctx->dt, \
+                                       ctx->d_node_vertex, ctx->d_node_side, ctx->d_pair_ptr, ctx->d_pair_col, ctx->d_pair_M, f, src,                     \
+                                       ctx->have_sources ? 1 : 0, ctx->d_node_gv, ctx->d_gdiag, ctx->d_gcptr, ctx->d_gc_facet, ctx->d_gc_lab, ctx->d_fvec, b)
+    if (g.n_nodes_owned > 0) {
+        switch (ctx->pc_group) {
+            case 4: KNP_RHS(4); break;
+            case 8: KNP_RHS(8); break;
+            case 16: KNP_RHS(16); break;
+            default: KNP_RHS(32); break;
+        }
+    }
+#undef KNP_RHS
     launch_schur_diag(ctx, f);   // before a possible knp_gmres_prepare forks the side stream (it reads d_cc)
     HIPCHK(hipGetLastError());
     return KNP_OK;
@@ -2031,28 +2124,14 @@ static int ensure_work(knp_ctx* ctx, int restart) {
 
 static int spmv_A(knp_ctx* ctx, double* x, const double* b, double* y, bool residual) {
     KCHK(halo_update(ctx, x));
-    if (ctx->spmv_group > 0) {
-        const KnpHostGraph& g = ctx->g;
-        hipEvent_t ea = nullptr, eb = nullptr;
-        if (ctx->prof_on & 1) {   // class 0: events tied to the kernel's begin / end
-            if (hipEventCreate(&ea) != hipSuccess || hipEventCreate(&eb) != hipSuccess) { ea = eb = nullptr; }
-        }
-        if (residual)
-            launch_spmv_node<1>(ctx->stream, ctx->spmv_group, g.n_nodes_owned, ctx->d_pair_ptr, ctx->d_pair_col, ctx->d_rowptr,
-                                ctx->d_colind, ctx->d_vals, x, b, y, ea, eb);
-        else
-            launch_spmv_node<0>(ctx->stream, ctx->spmv_group, g.n_nodes_owned, ctx->d_pair_ptr, ctx->d_pair_col, ctx->d_rowptr,
-                                ctx->d_colind, ctx->d_vals, x, b, y, ea, eb);
-        if (ea && eb) ctx->prof_recs.push_back({ea, eb, 0});
-        HIPCHK(hipGetLastError());
-        return KNP_OK;
+    const KnpHostGraph& g = ctx->g;
+    hipEvent_t ea = nullptr, eb = nullptr;
+    if (ctx->prof_on & 1) {   // class 0: events tied to the kernel's begin / end
+        if (hipEventCreate(&ea) != hipSuccess || hipEventCreate(&eb) != hipSuccess) { ea = eb = nullptr; }
     }
-    ProfScope ps(ctx, 0);
-    const int lanes = pick_lanes(ctx->n_dof_owned ? (double)ctx->nnz / ctx->n_dof_owned : 1.0);
-    if (residual)
-        launch_spmv<1, 1>(ctx->stream, lanes, ctx->n_dof_owned, ctx->d_rowptr, ctx->d_colind, ctx->d_vals, x, b, y);
-    else
-        launch_spmv<0, 1>(ctx->stream, lanes, ctx->n_dof_owned, ctx->d_rowptr, ctx->d_colind, ctx->d_vals, x, b, y);
+    if (residual) launch_spmv_node<1>(ctx, g.n_nodes_owned, nullptr, x, b, y, ea, eb);
+    else launch_spmv_node<0>(ctx, g.n_nodes_owned, nullptr, x, b, y, ea, eb);
+    if (ea && eb) ctx->prof_recs.push_back({ea, eb, 0});
     HIPCHK(hipGetLastError());
     return KNP_OK;
 }
@@ -2575,7 +2654,7 @@ int knp_pc_setup(knp_ctx* ctx, int32_t kind) {
     if (kind == KNP_PC_VBJACOBI && ctx->have_A) {
         const KnpHostGraph& g = ctx->g;
         hipLaunchKernelGGL(k_vbj_extract, dim3(nblocks(g.n_nodes_owned)), dim3(NT), 0, ctx->stream, g.n_nodes_owned,
-                           ctx->d_pair_ptr, ctx->d_pair_col, ctx->d_rowptr, ctx->d_vals, ctx->d_node_gv, ctx->d_gptr,
+                           ctx->d_pair_ptr, ctx->d_pair_col, ctx->d_ac, ctx->d_at, ctx->d_ax, ctx->d_node_gv, ctx->d_node_side,
                            ctx->d_gdiag, ctx->d_vbj);
         HIPCHK(hipGetLastError());
     }

@@ -136,7 +136,9 @@ int knp_build_graph(const knp_mesh_desc* m, KnpHostGraph& g) {
                 int c = nc[k] >> 2;
                 for (int b = 0; b < nv1; ++b) nbs.push_back(node_of(g, cells[(size_t)c * nv1 + b], side[c]));
             }
-            ncon[n + 1] = (int64_t)nbs.size();
+            // contributions of the self pair are not stored: sum_b K_ab(T) = 0 on every simplex, so the self entry of the
+            // concentration-weighted stiffness is minus the sum over the node's other pairs (k_assemble_nodes)
+            ncon[n + 1] = (int64_t)nbs.size() - (nc_ptr[n + 1] - nc_ptr[n]);
             std::sort(nbs.begin(), nbs.end());
             npair[n + 1] = (int32_t)(std::unique(nbs.begin(), nbs.end()) - nbs.begin());
         }
@@ -184,9 +186,11 @@ int knp_build_graph(const knp_mesh_desc* m, KnpHostGraph& g) {
                 double dot = 0;
                 for (int k = 0; k < dim; ++k) dot += G[t.la][k] * G[t.lb][k];
                 double kab = vol * dot;
-                g.contrib_cell[cc] = t.cell;
-                g.contrib_k[cc] = kab;
-                ++cc;
+                if (t.nb != n) {
+                    g.contrib_cell[cc] = t.cell;
+                    g.contrib_k[cc] = kab;
+                    ++cc;
+                }
                 g.pair_K[p] += kab;
                 g.pair_M[p] += vol * mfac * (t.la == t.lb ? 2.0 : 1.0);
             }
@@ -299,24 +303,36 @@ int knp_build_graph(const knp_mesh_desc* m, KnpHostGraph& g) {
         g.gx_e[s] = nbi;  // cross column of the extra row  = intra node of the neighbour
     }
 
-    // ---- 5. CSR pattern of A ----------------------------------------------------------------
-    // row (n,j<3): [ (nb,j),(nb,3) for nb in pairs ] ++ [ (cross,3) ]   length 2*deg + xp
-    // row (n,3)  : [ (nb,0..3) for nb in pairs ]     ++ [ (cross,3) ]   length 4*deg + xp
-    // xp = number of cross columns rounded up to even (one explicit zero on the node's own potential
-    // column when odd): every row then starts at an even index, i.e. 16-byte aligned for vector loads.
+    // ---- 5. size of A (the CSR pattern itself is built on demand: knp_build_csr_pattern) ----------------------------
+    {
+        int64_t nnz = 10 * np;
+        for (int n = 0; n < no; ++n) {
+            int A = g.node_gv[n];
+            if (A >= 0) nnz += 4 * (int64_t)(g.gptr[A + 1] - g.gptr[A]);
+        }
+        if (nnz > 0x7fffffffLL) { g.error = "nnz exceeds int32"; return KNP_E_MESH; }
+        g.nnz = nnz;
+    }
+    return KNP_OK;
+}
+
+// CSR pattern of A in the documented row order (export / parity hook):
+//   row (n,j<3): [ (nb,j),(nb,3) for nb in pairs ] ++ [ (cross,3) ]   length 2*deg + x
+//   row (n,3)  : [ (nb,0..3) for nb in pairs ]     ++ [ (cross,3) ]   length 4*deg + x
+int knp_build_csr_pattern(KnpHostGraph& g) {
+    const int no = g.n_nodes_owned;
+    if (!g.rowptr.empty()) return KNP_OK;
     g.rowptr.assign((size_t)4 * no + 1, 0);
     int64_t nnz = 0;
     for (int n = 0; n < no; ++n) {
         int deg = g.pair_ptr[n + 1] - g.pair_ptr[n];
         int A = g.node_gv[n];
         int x = A >= 0 ? g.gptr[A + 1] - g.gptr[A] : 0;
-        int xp = (x + 1) & ~1;
         for (int f = 0; f < 4; ++f) {
             g.rowptr[(size_t)4 * n + f] = (int32_t)nnz;
-            nnz += (f < 3 ? 2 : 4) * (int64_t)deg + xp;
+            nnz += (f < 3 ? 2 : 4) * (int64_t)deg + x;
         }
     }
-    if (nnz > 0x7fffffffLL) { g.error = "nnz exceeds int32"; return KNP_E_MESH; }
     g.rowptr[(size_t)4 * no] = (int32_t)nnz;
     g.colind.resize(nnz);
 #pragma omp parallel for schedule(static)
@@ -330,13 +346,11 @@ int knp_build_graph(const knp_mesh_desc* m, KnpHostGraph& g) {
             int32_t* ci = &g.colind[g.rowptr[(size_t)4 * n + f]];
             for (int q = 0; q < deg; ++q) { ci[2 * q] = 4 * g.pair_col[p0 + q] + f; ci[2 * q + 1] = 4 * g.pair_col[p0 + q] + 3; }
             for (int r = 0; r < x; ++r) ci[2 * deg + r] = 4 * cross[r] + 3;
-            if (x & 1) ci[2 * deg + x] = 4 * n + 3;   // padding entry, value stays 0
         }
         int32_t* ci = &g.colind[g.rowptr[(size_t)4 * n + 3]];
         for (int q = 0; q < deg; ++q)
             for (int f = 0; f < 4; ++f) ci[4 * q + f] = 4 * g.pair_col[p0 + q] + f;
         for (int r = 0; r < x; ++r) ci[4 * deg + r] = 4 * cross[r] + 3;
-        if (x & 1) ci[4 * deg + x] = 4 * n + 3;
     }
     return KNP_OK;
 }
