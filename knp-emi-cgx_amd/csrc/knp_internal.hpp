@@ -242,6 +242,9 @@ struct knp_ctx {
     int32_t* d_defl_mode = nullptr;
     double* d_defl_einv = nullptr;
     double* d_y = nullptr;       // [restart+1]
+    double* d_gm = nullptr;      // GMRES bookkeeping on the device (GmLayout: Hessenberg columns, rotations, g, y, state)
+    int gm_cap = 0;
+    int64_t n_norm_fallback = 0; // iterations that needed the explicit norm (second reduction)
     int n_red_blocks = 0;
     // comm
     knp_halo_fn halo = nullptr;

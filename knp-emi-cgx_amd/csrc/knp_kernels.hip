@@ -85,6 +85,27 @@ __device__ __forceinline__ double block_sum(double v, double* sm) {
     return r;
 }
 
+// Part of a CSR row dot product, L lanes per row, four independent gathers in flight per lane.  These rows are short (3-40
+// entries): with one entry per lane per trip the dependent chain rowptr -> (col, val) -> x[col] leaves ~8 B per lane in flight
+// and the kernel runs at HBM *latency*; issuing four predicated trips at once keeps the memory system busy instead
+// (clamped indices re-read the row's last entry, the products of the surplus trips are dropped).
+template <int L, typename VT>
+__device__ __forceinline__ double row_dot4(int k0, int e, int lane, const int32_t* __restrict__ ci, const VT* __restrict__ v,
+                                           const double* __restrict__ x) {
+    double s = 0.0;
+    for (int k = k0 + lane; k < e; k += 4 * L) {
+        const int kb = min(k + L, e - 1), kc = min(k + 2 * L, e - 1), kd = min(k + 3 * L, e - 1);
+        const int ca = ci[k], cb = ci[kb], cc = ci[kc], cd = ci[kd];
+        const double va = (double)v[k], vb = (double)v[kb], vc = (double)v[kc], vd = (double)v[kd];
+        const double xa = x[ca], xb = x[cb], xc = x[cc], xd = x[cd];
+        s += va * xa;
+        if (k + L < e) s += vb * xb;
+        if (k + 2 * L < e) s += vc * xc;
+        if (k + 3 * L < e) s += vd * xd;
+    }
+    return s;
+}
+
 // ------------------------------------------------------------------------------------------
 // K0: cell means
 // ------------------------------------------------------------------------------------------
@@ -156,14 +177,22 @@ k_assemble_nodes(int n_nodes, DevParams P, const int32_t* __restrict__ pair_ptr,
         if (pair_col[p] == node) { self_p = p; continue; }
         double S0 = 0.0, S1 = 0.0, S2 = 0.0;
         const int c1 = contrib_ptr[p + 1];
-        for (int c = contrib_ptr[p]; c < c1; ++c) {
-            const int cell = contrib_cell[c];
-            const double k = contrib_k[c];
+        for (int c = contrib_ptr[p]; c < c1; c += 2) {   // two cells in flight (an edge has 2 cells in 2D, ~5 in 3D)
+            const int cb = min(c + 1, c1 - 1);
+            const int cell = contrib_cell[c], cell2 = contrib_cell[cb];
+            const double k = contrib_k[c], k2 = contrib_k[cb];
             const double2 c01 = *reinterpret_cast<const double2*>(cbar + (size_t)4 * cell);
             const double c2 = cbar[(size_t)4 * cell + 2];
+            const double2 d01 = *reinterpret_cast<const double2*>(cbar + (size_t)4 * cell2);
+            const double d2 = cbar[(size_t)4 * cell2 + 2];
             S0 += k * c01.x;
             S1 += k * c01.y;
             S2 += k * c2;
+            if (c + 1 < c1) {
+                S0 += k2 * d01.x;
+                S1 += k2 * d01.y;
+                S2 += k2 * d2;
+            }
         }
         if (live) emit(p, S0, S1, S2);
         T0 += S0; T1 += S1; T2 += S2;
@@ -324,10 +353,7 @@ k_spmv(int n_rows, const int32_t* __restrict__ rp, const int32_t* __restrict__ c
     const int row = gid / L;
     const int lane = threadIdx.x & (L - 1);
     double s = 0.0;
-    if (row < n_rows) {
-        const int e = rp[row + 1];
-        for (int k = rp[row] + lane; k < e; k += L) s += (double)v[k] * x[ci[k]];
-    }
+    if (row < n_rows) s = row_dot4<L, VT>(rp[row], rp[row + 1], lane, ci, v, x);
 #pragma unroll
     for (int o = L >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, L);
     if (lane == 0 && row < n_rows) {
@@ -558,11 +584,16 @@ k_phi_rhs(int n_nodes, double z0, double z1, double z2, const int32_t* __restric
     if (node < n_nodes) {
         const int p0 = pair_ptr[node];
         const int deg = pair_ptr[node + 1] - p0;
-        for (int q = lane; q < deg; q += G) {
-            const int nb = pair_col[p0 + q];
+        for (int q = lane; q < deg; q += 2 * G) {   // two predicated trips in flight per lane
+            const int q2 = min(q + G, deg - 1);
+            const int nb = pair_col[p0 + q], nb2 = pair_col[p0 + q2];
+            const double m1 = pair_M[p0 + q], m2 = pair_M[p0 + q2];
             const double2 za = *reinterpret_cast<const double2*>(z + 4 * (size_t)nb);
             const double zc = z[4 * (size_t)nb + 2];
-            s += pair_M[p0 + q] * (z0 * za.x + z1 * za.y + z2 * zc);
+            const double2 ya = *reinterpret_cast<const double2*>(z + 4 * (size_t)nb2);
+            const double yc = z[4 * (size_t)nb2 + 2];
+            s += m1 * (z0 * za.x + z1 * za.y + z2 * zc);
+            if (q + G < deg) s += m2 * (z0 * ya.x + z1 * ya.y + z2 * yc);
         }
     }
 #pragma unroll
@@ -648,10 +679,7 @@ k_prolong_rows(int n_act, const int32_t* __restrict__ rows, const int32_t* __res
     const int i = gid / L;
     const int lane = threadIdx.x & (L - 1);
     double s = 0.0;
-    if (i < n_act) {
-        const int e = rp[i + 1];
-        for (int k = rp[i] + lane; k < e; k += L) s += (double)v[k] * x[ci[k]];
-    }
+    if (i < n_act) s = row_dot4<L, VT>(rp[i], rp[i + 1], lane, ci, v, x);
 #pragma unroll
     for (int o = L >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, L);
     if (lane == 0 && i < n_act) y[rows[i]] += s;
@@ -679,10 +707,7 @@ k_restrict_first(int n_rows, const int32_t* __restrict__ rp, const int32_t* __re
     const int row = gid / L;
     const int lane = threadIdx.x & (L - 1);
     double s = 0.0;
-    if (row < n_rows) {
-        const int e = rp[row + 1];
-        for (int k = rp[row] + lane; k < e; k += L) s += (double)v[k] * x[ci[k]];
-    }
+    if (row < n_rows) s = row_dot4<L, VT>(rp[row], rp[row + 1], lane, ci, v, x);
 #pragma unroll
     for (int o = L >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, L);
     if (lane == 0 && row < n_rows) {
@@ -724,26 +749,52 @@ k_l0_down(int n_nodes, const int32_t* __restrict__ pair_ptr, const int32_t* __re
     if (node < n_nodes) {
         const int p0 = pair_ptr[node];
         const int deg = pair_ptr[node + 1] - p0;
-        for (int q = lane; q < deg; q += G) {
-            const int nb = pair_col[p0 + q];
-            if (FM == 2) {
-                s3 += (double)pt[p0 + q] * b[nb];
-            } else {
-                double a0, a1, a2, a3;
+        if (FM == 2) {   // 4 B value + 4 B index + 8 B gather per pair: four predicated trips in flight per lane (see row_dot4)
+            const int32_t* __restrict__ col = pair_col + p0;
+            const VT* __restrict__ val = pt + p0;
+            for (int q = lane; q < deg; q += 4 * G) {
+                const int qb = min(q + G, deg - 1), qc = min(q + 2 * G, deg - 1), qd = min(q + 3 * G, deg - 1);
+                const int na = col[q], nb = col[qb], nc = col[qc], nd = col[qd];
+                const double va = (double)val[q], vb = (double)val[qb], vc = (double)val[qc], vd = (double)val[qd];
+                const double xa = b[na], xb = b[nb], xc = b[nc], xd = b[nd];
+                s3 += va * xa;
+                if (q + G < deg) s3 += vb * xb;
+                if (q + 2 * G < deg) s3 += vc * xc;
+                if (q + 3 * G < deg) s3 += vd * xd;
+            }
+        } else {         // two predicated trips in flight per lane: 2 x (4 B index + 16/32 B values + 32 B gather)
+            for (int q = lane; q < deg; q += 2 * G) {
+                const int q2 = min(q + G, deg - 1);
+                const bool h2 = q + G < deg;
+                const int nb = pair_col[p0 + q], nb2 = pair_col[p0 + q2];
+                double a0, a1, a2, a3, e0, e1, e2, e3;
                 if (sizeof(VT) == 4) {
                     const float4 pq = *reinterpret_cast<const float4*>(pt + 4 * (size_t)(p0 + q));
+                    const float4 pr = *reinterpret_cast<const float4*>(pt + 4 * (size_t)(p0 + q2));
                     a0 = pq.x; a1 = pq.y; a2 = pq.z; a3 = pq.w;
+                    e0 = pr.x; e1 = pr.y; e2 = pr.z; e3 = pr.w;
                 } else {
                     const double2 u = *reinterpret_cast<const double2*>(pt + 4 * (size_t)(p0 + q));
                     const double2 w = *reinterpret_cast<const double2*>(pt + 4 * (size_t)(p0 + q) + 2);
+                    const double2 u2 = *reinterpret_cast<const double2*>(pt + 4 * (size_t)(p0 + q2));
+                    const double2 w2 = *reinterpret_cast<const double2*>(pt + 4 * (size_t)(p0 + q2) + 2);
                     a0 = u.x; a1 = u.y; a2 = w.x; a3 = w.y;
+                    e0 = u2.x; e1 = u2.y; e2 = w2.x; e3 = w2.y;
                 }
                 const double2 xa = *reinterpret_cast<const double2*>(b + 4 * (size_t)nb);
                 const double2 xb = *reinterpret_cast<const double2*>(b + 4 * (size_t)nb + 2);
+                const double2 ya = *reinterpret_cast<const double2*>(b + 4 * (size_t)nb2);
+                const double2 yb = *reinterpret_cast<const double2*>(b + 4 * (size_t)nb2 + 2);
                 s0 += a0 * xa.x;
                 s1 += a1 * xa.y;
                 s2 += a2 * xb.x;
                 if (FM == 0) s3 += a3 * xb.y;
+                if (h2) {
+                    s0 += e0 * ya.x;
+                    s1 += e1 * ya.y;
+                    s2 += e2 * yb.x;
+                    if (FM == 0) s3 += e3 * yb.y;
+                }
             }
         }
     }
@@ -772,6 +823,7 @@ template <int FM, typename VT>
 static void launch_l0_down_t(hipStream_t st, int G, int n_nodes, const int32_t* pp, const int32_t* pc, const VT* pt, const double* b, double c, double* r) {
     if (n_nodes <= 0) return;
     switch (G) {
+        case 2: hipLaunchKernelGGL((k_l0_down<2, FM, VT>), dim3(nblocks((int64_t)n_nodes * 2)), dim3(NT), 0, st, n_nodes, pp, pc, pt, b, c, r); break;
         case 4: hipLaunchKernelGGL((k_l0_down<4, FM, VT>), dim3(nblocks((int64_t)n_nodes * 4)), dim3(NT), 0, st, n_nodes, pp, pc, pt, b, c, r); break;
         case 8: hipLaunchKernelGGL((k_l0_down<8, FM, VT>), dim3(nblocks((int64_t)n_nodes * 8)), dim3(NT), 0, st, n_nodes, pp, pc, pt, b, c, r); break;
         case 16: hipLaunchKernelGGL((k_l0_down<16, FM, VT>), dim3(nblocks((int64_t)n_nodes * 16)), dim3(NT), 0, st, n_nodes, pp, pc, pt, b, c, r); break;
@@ -797,18 +849,26 @@ k_level_up(int n_act, const int32_t* __restrict__ rows, const int32_t* __restric
     const int i = gid / L;
     const int lane = threadIdx.x & (L - 1);
     double s = 0.0;
+    int row = 0;
+    double di = 0.0, bi = 0.0, ri = 0.0, x0 = 0.0, ci_ = 0.0;
     if (i < n_act) {
-        const int e = rp[i + 1];
-        for (int k = rp[i] + lane; k < e; k += L) s += (double)v[k] * xc[ci[k]];
+        const int k0 = rp[i], e = rp[i + 1];
+        if (lane == 0) {   // the epilogue's operands travel together with the gathers instead of after the reduction
+            row = rows ? rows[i] : i;
+            di = dinv[row];
+            ri = r[row];
+            if (xin) x0 = xin[row];
+            if (!xin || MODE == 1) bi = b[row];
+            if (MODE == 1) ci_ = cc[row];
+        }
+        s = row_dot4<L, VT>(k0, e, lane, ci, v, xc);
     }
 #pragma unroll
     for (int o = L >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, L);
     if (lane == 0 && i < n_act) {
-        const int row = rows ? rows[i] : i;
-        const double di = dinv[row];
-        const double base = xin ? xin[row] : c * di * b[row];
-        const double out = base + c2 * di * r[row] + s;
-        if (MODE == 1) z[4 * (size_t)row + 3] = out + cc[row] * b[row];
+        const double base = xin ? x0 : c * di * bi;
+        const double out = base + c2 * di * ri + s;
+        if (MODE == 1) z[4 * (size_t)row + 3] = out + ci_ * bi;
         else z[row] = out;
     }
 }
@@ -873,18 +933,21 @@ static int pick_lanes(double avg_nnz_per_row, int role = 0) {   // role 0 level 
 // partial[(i)*RED_BLOCKS + blk] = sum over this block's elements of V_i . w, i = i0 .. i0+G-1 (< m)
 // NS: additionally accumulate the sum of the potential entries of w into row `m` of partial -- the coefficient
 // of w along the (unnormalised) null-space vector, so that the gauge projection rides on the same reduction.
-template <int G, bool NS>
+// WW: also accumulate w.w into the row after those (row m + NS): with it the norm of the orthogonalised vector follows from
+// the same reduction (Pythagoras), and one all-reduce per GMRES iteration is enough.
+template <int G, bool NS, bool WW>
 __global__ void __launch_bounds__(NT)
 k_multi_dot(int n, int64_t ldv, int i0, int m, const double* __restrict__ V, const double* __restrict__ w,
             double* __restrict__ partial) {
     __shared__ double sm[NT / 64];
     double acc[G];
-    double ans = 0.0;
+    double ans = 0.0, aww = 0.0;
 #pragma unroll
     for (int g = 0; g < G; ++g) acc[g] = 0.0;
     for (int e = blockIdx.x * NT + threadIdx.x; e < n; e += gridDim.x * NT) {
         const double we = w[e];
         if (NS && (e & 3) == 3) ans += we;
+        if (WW) aww += we * we;
 #pragma unroll
         for (int g = 0; g < G; ++g)
             if (i0 + g < m) acc[g] += V[(int64_t)(i0 + g) * ldv + e] * we;
@@ -897,6 +960,10 @@ k_multi_dot(int n, int64_t ldv, int i0, int m, const double* __restrict__ V, con
     if (NS) {
         double r = block_sum(ans, sm);
         if (threadIdx.x == 0) partial[(size_t)m * RED_BLOCKS + blockIdx.x] = r;
+    }
+    if (WW) {
+        double r = block_sum(aww, sm);
+        if (threadIdx.x == 0) partial[(size_t)(m + (NS ? 1 : 0)) * RED_BLOCKS + blockIdx.x] = r;
     }
 }
 
@@ -962,6 +1029,113 @@ __global__ void __launch_bounds__(NT) k_lincomb(int n, int64_t ldv, int m, const
         double xe = x[e];
         for (int i = 0; i < m; ++i) xe += y[i] * V[(int64_t)i * ldv + e];
         x[e] = xe;
+    }
+}
+
+// ---- GMRES bookkeeping on the device (one wave): the host only reads back the residual estimate and a flag --------
+// gm layout (doubles): H [(m+1) x m, column major] | cs [m] | sn [m] | g [m+1] | y [m] | state {||w'||^2, flag, residual}
+struct GmLayout {
+    int m;
+    __host__ __device__ int H(int i, int j) const { return i + j * (m + 1); }
+    __host__ __device__ int cs() const { return (m + 1) * m; }
+    __host__ __device__ int sn() const { return cs() + m; }
+    __host__ __device__ int g() const { return sn() + m; }
+    __host__ __device__ int y() const { return g() + m + 1; }
+    __host__ __device__ int st() const { return y() + m; }
+    __host__ __device__ int size() const { return st() + 8; }
+};
+static constexpr double GM_CANCEL = 1e-4;   // ||w'||^2 < GM_CANCEL ||w||^2: Pythagoras loses > 4 digits, take the explicit norm
+
+__global__ void k_gm_init(GmLayout L, double* __restrict__ gm, const double* __restrict__ beta2) {
+    const int t = threadIdx.x;
+    for (int i = t; i <= L.m; i += blockDim.x) gm[L.g() + i] = (i == 0) ? sqrt(*beta2) : 0.0;
+}
+
+// column j of the Hessenberg matrix from the reduced values red = {h_0..h_j, [ns sum], w.w}: norm of the orthogonalised vector by
+// Pythagoras (or, explicit_slot >= 0, the explicitly reduced one), previous Givens rotations, the new rotation, the residual
+// estimate |g_{j+1}|; published to pinned host memory together with the sequence word the host spins on.
+__global__ void k_givens(GmLayout L, int j, int has_ns, double inv_cnt, const double* __restrict__ red, int explicit_slot,
+                         double* __restrict__ gm, double* mirror, volatile int64_t* seq, int64_t seq_val) {
+    if (threadIdx.x != 0) return;
+    double* st = gm + L.st();
+    double nrm2;
+    bool cancel = false;
+    if (explicit_slot < 0) {
+        const double ww = red[j + 1 + has_ns];
+        double s = 0.0;
+        for (int i = 0; i <= j; ++i) s += red[i] * red[i];
+        if (has_ns) s += red[j + 1] * red[j + 1] * inv_cnt;   // component along the normalised null-space vector
+        nrm2 = ww - s;
+        cancel = !(nrm2 > GM_CANCEL * ww) && ww > 0.0;        // (NaNs fall through to the breakdown test below)
+    } else {
+        nrm2 = red[explicit_slot];
+    }
+    double flag = 0.0, res = 0.0;
+    if (cancel) {
+        flag = 1.0;
+        nrm2 = 1.0;
+    } else {
+        double* h = gm + L.H(0, j);
+        for (int i = 0; i <= j; ++i) h[i] = red[i];
+        h[j + 1] = sqrt(fmax(nrm2, 0.0));
+        double* cs = gm + L.cs();
+        double* sn = gm + L.sn();
+        double* g = gm + L.g();
+        for (int i = 0; i < j; ++i) {
+            const double t = cs[i] * h[i] + sn[i] * h[i + 1];
+            h[i + 1] = -sn[i] * h[i] + cs[i] * h[i + 1];
+            h[i] = t;
+        }
+        const double den = hypot(h[j], h[j + 1]);
+        if (!(den > 0.0) || !isfinite(den) || !(nrm2 == nrm2)) {
+            flag = 2.0;
+            nrm2 = 1.0;
+        } else {
+            cs[j] = h[j] / den;
+            sn[j] = h[j + 1] / den;
+            h[j] = den;
+            h[j + 1] = 0.0;
+            g[j + 1] = -sn[j] * g[j];
+            g[j] = cs[j] * g[j];
+            res = fabs(g[j + 1]);
+            if (!(nrm2 > 0.0)) nrm2 = 1.0;   // exact breakdown (w' = 0): the next basis vector is irrelevant, avoid 1/0
+        }
+    }
+    st[0] = nrm2; st[1] = flag; st[2] = res;
+    if (mirror) { mirror[0] = res; mirror[1] = flag; }
+    if (seq) {
+        __threadfence_system();
+        *seq = seq_val;
+    }
+}
+
+// v_{j+1} = (w - sum_i h[i] V_i - gauge part) / ||.||  in one pass (state: {||w'||^2, flag}); with flag != 0 the vector is left
+// unnormalised (the explicit-norm fallback normalises it afterwards)
+__global__ void __launch_bounds__(NT)
+k_update_scale(int n, int64_t ldv, int m, const double* __restrict__ V, const double* __restrict__ h, const double* __restrict__ w,
+               const double* __restrict__ st, double ns_scale, double* __restrict__ out) {
+    const double inv = st[1] == 0.0 ? 1.0 / sqrt(st[0]) : 1.0;
+    const double mean = ns_scale != 0.0 ? h[m] * ns_scale : 0.0;
+    for (int e = blockIdx.x * NT + threadIdx.x; e < n; e += gridDim.x * NT) {
+        double we = w[e];
+        if ((e & 3) == 3) we -= mean;
+        for (int i = 0; i < m; ++i) we -= h[i] * V[(int64_t)i * ldv + e];
+        out[e] = we * inv;
+    }
+}
+__global__ void __launch_bounds__(NT) k_scale_inplace_rsqrt(int n, const double* __restrict__ nrm2, double* __restrict__ v) {
+    const double inv = 1.0 / sqrt(*nrm2);
+    for (int e = blockIdx.x * NT + threadIdx.x; e < n; e += gridDim.x * NT) v[e] *= inv;
+}
+// y = H(0:jd,0:jd)^-1 g(0:jd) (upper triangular after the rotations)
+__global__ void k_gm_solve_y(GmLayout L, int jd, double* __restrict__ gm) {
+    if (threadIdx.x != 0) return;
+    double* y = gm + L.y();
+    const double* g = gm + L.g();
+    for (int i = jd - 1; i >= 0; --i) {
+        double s = g[i];
+        for (int k = i + 1; k < jd; ++k) s -= gm[L.H(i, k)] * y[k];
+        y[i] = s / gm[L.H(i, i)];
     }
 }
 
@@ -1169,10 +1343,7 @@ k_cheby_step(int n_rows, const int32_t* __restrict__ rp, const int32_t* __restri
     const int row = gid / L;
     const int lane = threadIdx.x & (L - 1);
     double s = 0.0;
-    if (row < n_rows) {
-        const int e = rp[row + 1];
-        for (int k = rp[row] + lane; k < e; k += L) s += (double)v[k] * xin[ci[k]];
-    }
+    if (row < n_rows) s = row_dot4<L, VT>(rp[row], rp[row + 1], lane, ci, v, xin);
 #pragma unroll
     for (int o = L >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, L);
     if (lane == 0 && row < n_rows) {
@@ -1589,7 +1760,7 @@ int knp_destroy(knp_ctx* ctx) {
     dev_free(ctx->d_at); dev_free(ctx->d_ac); dev_free(ctx->d_ax); dev_free(ctx->d_gx_i); dev_free(ctx->d_gx_e);
     dev_free(ctx->d_p_vals);
     dev_free(ctx->d_cbar); dev_free(ctx->d_fmat); dev_free(ctx->d_fvec);
-    dev_free(ctx->d_partial); dev_free(ctx->d_red); dev_free(ctx->d_y); dev_free(ctx->d_vbj);
+    dev_free(ctx->d_partial); dev_free(ctx->d_red); dev_free(ctx->d_y); dev_free(ctx->d_vbj); dev_free(ctx->d_gm);
     if (ctx->h_red) (void)hipHostFree(ctx->h_red);
     if (ctx->h_seq) (void)hipHostFree((void*)ctx->h_seq);
     dev_free(ctx->d_V); dev_free(ctx->d_w); dev_free(ctx->d_t);
@@ -2572,8 +2743,9 @@ static void amg_cycle_fused(knp_ctx* ctx, KnpAmgHier& H, const double* b, double
     const double c0 = cheb_c(L0);
     const int nn = ctx->g.n_nodes_owned;
     if (phi) {
-        if (H.pt_phi_f) launch_l0_down<float>(st, 2, ctx->pc_group, nn, ctx->d_pair_ptr, ctx->d_pair_col, H.pt_phi_f, b, c0, L0.r);
-        else launch_l0_down<double>(st, 2, ctx->pc_group, nn, ctx->d_pair_ptr, ctx->d_pair_col, H.pt_phi, b, c0, L0.r);
+        const int Gp = std::max(2, ctx->pc_group / 2);   // four trips per lane in flight: a quarter of the pairs per lane
+        if (H.pt_phi_f) launch_l0_down<float>(st, 2, Gp, nn, ctx->d_pair_ptr, ctx->d_pair_col, H.pt_phi_f, b, c0, L0.r);
+        else launch_l0_down<double>(st, 2, Gp, nn, ctx->d_pair_ptr, ctx->d_pair_col, H.pt_phi, b, c0, L0.r);
     } else {
         if (H.pt_f) launch_l0_down<float>(st, fm, ctx->pc_group, nn, ctx->d_pair_ptr, ctx->d_pair_col, H.pt_f, b, c0, L0.r);
         else launch_l0_down<double>(st, fm, ctx->pc_group, nn, ctx->d_pair_ptr, ctx->d_pair_col, H.pt, b, c0, L0.r);
@@ -2833,8 +3005,33 @@ int knp_gmres_solve(knp_ctx* ctx, const double* b, double* x, double rtol, doubl
     const int64_t cnt = ctx->ns_on ? global_phi_count(ctx, &rc) : 0;
     if (ctx->ns_on) KCHK(rc);
     const int m = restart;
-    std::vector<double> H((size_t)(m + 1) * m, 0.0), g(m + 1, 0.0), cs(m, 0.0), sn(m, 0.0), y(m, 0.0);
-    auto Hx = [&](int i, int j) -> double& { return H[(size_t)i + (size_t)j * (m + 1)]; };
+    const GmLayout GL{m};
+    if (ctx->gm_cap < GL.size()) {
+        HIPCHK(hipStreamSynchronize(st));
+        dev_free(ctx->d_gm);
+        HIPCHK(hipMalloc((void**)&ctx->d_gm, (size_t)GL.size() * sizeof(double)));
+        HIPCHK(hipMemset(ctx->d_gm, 0, (size_t)GL.size() * sizeof(double)));
+        ctx->gm_cap = GL.size();
+    }
+    double* gm = ctx->d_gm;
+    // residual estimate and flag of the last k_givens: pinned mirror (slots GM_RES, GM_RES+1) + sequence word, or a copy on the hook path
+    constexpr int GM_RES = 100, GM_EXPL = 57;
+    auto read_state = [&](double& res_out, int& flag_out) -> int {
+        ++ctx->n_readback;
+        if (ctx->mirror() && ctx->h_seq_dev) {
+            KCHK(read_slots_inner(ctx, GM_RES, 2, ctx->seq_counter));
+            if (ctx->p2p) KCHK(knp_p2p_check(ctx));
+            res_out = ctx->h_red[GM_RES];
+            flag_out = (int)ctx->h_red[GM_RES + 1];
+        } else {
+            double tmp[3];
+            HIPCHK(hipMemcpyAsync(tmp, gm + GL.st(), 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            res_out = tmp[2];
+            flag_out = (int)tmp[1];
+        }
+        return KNP_OK;
+    };
 
     // ||M b|| for the relative tolerance (non-zero initial guess, preconditioned norm)
     if (ctx->prep_b == b && restart == ctx->gm_restart) {   // already computed on the side stream (knp_gmres_prepare)
@@ -2857,6 +3054,9 @@ int knp_gmres_solve(knp_ctx* ctx, const double* b, double* x, double rtol, doubl
     int it = 0;
     double res = 0.0, res0 = -1.0;
     *reason = 0;
+    const bool ns = ctx->ns_on && cnt > 0;
+    const int nsi = ns ? 1 : 0;
+    const int vec_blocks = std::min(nblocks(n), 2048);
     while (true) {
         // r = M (b - A x)
         KCHK(spmv_A(ctx, x, b, ctx->d_t, true));
@@ -2869,77 +3069,64 @@ int knp_gmres_solve(knp_ctx* ctx, const double* b, double* x, double rtol, doubl
         if (!std::isfinite(beta)) { *reason = KNP_DIVERGED_NANORINF; break; }
         if (beta <= ttol) { *reason = (beta <= atol) ? KNP_CONVERGED_ATOL : KNP_CONVERGED_RTOL; break; }
         if (it >= max_it) { *reason = KNP_DIVERGED_ITS; break; }
-        hipLaunchKernelGGL(k_scale_rsqrt, dim3(std::min(nblocks(n), 2048)), dim3(NT), 0, st, n, ctx->d_w, ctx->d_red + 60, ctx->d_V);
-        std::fill(g.begin(), g.end(), 0.0);
-        g[0] = beta;
+        hipLaunchKernelGGL(k_scale_rsqrt, dim3(vec_blocks), dim3(NT), 0, st, n, ctx->d_w, ctx->d_red + 60, ctx->d_V);
+        hipLaunchKernelGGL(k_gm_init, dim3(1), dim3(64), 0, st, GL, gm, ctx->d_red + 60);
         int jd = 0;
         bool stop = false;
         for (int j = 0; j < m; ++j) {
             double* vj = ctx->d_V + (size_t)j * ldv;
+            double* vn = ctx->d_V + (size_t)(j + 1) * ldv;
             KCHK(spmv_A(ctx, vj, nullptr, ctx->d_t, false));
             // The null-space removal that follows the preconditioner (KSP_RemoveNullSpace) is folded into the
             // Gram-Schmidt pass: the basis vectors are orthogonal to ns, so h_i = V_i.(w - ns ns.w) = V_i.w, and the
             // projection itself is one more "basis vector" in the update (same reduction, no extra all-reduce).
-            const bool ns = ctx->ns_on && cnt > 0;
             KCHK(pc_apply_proj(ctx, ctx->d_t, ctx->d_w, ns ? 0 : cnt));
+            int flag = 0;
             {
                 ProfScope ps(ctx, 1);
+                // ONE reduction per iteration: the j+1 Gram-Schmidt coefficients, the gauge coefficient and w.w; the norm of the
+                // orthogonalised vector follows by Pythagoras (explicit norm only when that would cancel, see k_givens)
                 for (int i0 = 0; i0 <= j; i0 += 8) {
-                    if (ns && i0 == 0)
-                        hipLaunchKernelGGL((k_multi_dot<8, true>), dim3(nb), dim3(NT), 0, st, n, ldv, i0, j + 1, ctx->d_V, ctx->d_w, ctx->d_partial);
+                    if (i0 == 0 && ns)
+                        hipLaunchKernelGGL((k_multi_dot<8, true, true>), dim3(nb), dim3(NT), 0, st, n, ldv, i0, j + 1, ctx->d_V, ctx->d_w, ctx->d_partial);
+                    else if (i0 == 0)
+                        hipLaunchKernelGGL((k_multi_dot<8, false, true>), dim3(nb), dim3(NT), 0, st, n, ldv, i0, j + 1, ctx->d_V, ctx->d_w, ctx->d_partial);
                     else
-                        hipLaunchKernelGGL((k_multi_dot<8, false>), dim3(nb), dim3(NT), 0, st, n, ldv, i0, j + 1, ctx->d_V, ctx->d_w, ctx->d_partial);
+                        hipLaunchKernelGGL((k_multi_dot<8, false, false>), dim3(nb), dim3(NT), 0, st, n, ldv, i0, j + 1, ctx->d_V, ctx->d_w, ctx->d_partial);
                 }
-                const int nred = j + 1 + (ns ? 1 : 0);
-                hipLaunchKernelGGL(k_reduce_partials, dim3(nred), dim3(NT), 0, st, nb, ctx->d_partial, ctx->d_red, 0, ctx->mirror());
+                const int nred = j + 2 + nsi;
+                hipLaunchKernelGGL(k_reduce_partials, dim3(nred), dim3(NT), 0, st, nb, ctx->d_partial, ctx->d_red, 0, (double*)nullptr);
                 KCHK(allreduce_slots(ctx, 0, nred));
-                hipLaunchKernelGGL(k_update_norm, dim3(nb), dim3(NT), 0, st, n, ldv, j + 1, ctx->d_V, ctx->d_red, ctx->d_w, ctx->d_partial,
-                                   ns ? 1.0 / (double)cnt : 0.0);
-                hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(NT), 0, st, nb, ctx->d_partial, ctx->d_red, j + 1, ctx->mirror(),
-                                   ctx->mirror() ? ctx->h_seq_dev : nullptr, ++ctx->seq_counter);
-                KCHK(allreduce_slots(ctx, j + 1, 1));
-                if (j + 1 < m + 1)
-                    hipLaunchKernelGGL(k_scale_rsqrt, dim3(std::min(nblocks(n), 2048)), dim3(NT), 0, st, n, ctx->d_w, ctx->d_red + j + 1,
-                                       ctx->d_V + (size_t)(j + 1) * ldv);
+                hipLaunchKernelGGL(k_givens, dim3(1), dim3(64), 0, st, GL, j, nsi, ns ? 1.0 / (double)cnt : 0.0, ctx->d_red, -1, gm,
+                                   ctx->mirror() ? ctx->h_red_dev + GM_RES : nullptr, ctx->mirror() ? ctx->h_seq_dev : nullptr, ++ctx->seq_counter);
+                hipLaunchKernelGGL(k_update_scale, dim3(nb), dim3(NT), 0, st, n, ldv, j + 1, ctx->d_V, ctx->d_red, ctx->d_w, gm + GL.st(),
+                                   ns ? 1.0 / (double)cnt : 0.0, vn);
                 HIPCHK(hipGetLastError());
             }
-            KCHK(read_slots(ctx, 0, j + 2, ctx->seq_counter));
-            const double hn = std::sqrt(std::max(ctx->h_red[j + 1], 0.0));
-            for (int i = 0; i <= j; ++i) Hx(i, j) = ctx->h_red[i];
-            Hx(j + 1, j) = hn;
-            for (int i = 0; i < j; ++i) {
-                const double t = cs[i] * Hx(i, j) + sn[i] * Hx(i + 1, j);
-                Hx(i + 1, j) = -sn[i] * Hx(i, j) + cs[i] * Hx(i + 1, j);
-                Hx(i, j) = t;
+            KCHK(read_state(res, flag));
+            if (flag == 1) {   // cancellation: explicit norm of the (unnormalised) vector, second reduction of this iteration
+                ProfScope ps(ctx, 1);
+                ++ctx->n_norm_fallback;
+                hipLaunchKernelGGL(k_dot, dim3(nb), dim3(NT), 0, st, n, vn, vn, ctx->d_partial);
+                hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(NT), 0, st, nb, ctx->d_partial, ctx->d_red, GM_EXPL, (double*)nullptr);
+                KCHK(allreduce_slots(ctx, GM_EXPL, 1));
+                hipLaunchKernelGGL(k_givens, dim3(1), dim3(64), 0, st, GL, j, nsi, ns ? 1.0 / (double)cnt : 0.0, ctx->d_red, GM_EXPL, gm,
+                                   ctx->mirror() ? ctx->h_red_dev + GM_RES : nullptr, ctx->mirror() ? ctx->h_seq_dev : nullptr, ++ctx->seq_counter);
+                hipLaunchKernelGGL(k_scale_inplace_rsqrt, dim3(vec_blocks), dim3(NT), 0, st, n, gm + GL.st(), vn);
+                HIPCHK(hipGetLastError());
+                KCHK(read_state(res, flag));
             }
-            const double den = std::hypot(Hx(j, j), Hx(j + 1, j));
-            if (!(den > 0.0) || !std::isfinite(den)) { *reason = KNP_DIVERGED_NANORINF; stop = true; jd = j; break; }
-            cs[j] = Hx(j, j) / den;
-            sn[j] = Hx(j + 1, j) / den;
-            Hx(j, j) = den;
-            Hx(j + 1, j) = 0.0;
-            g[j + 1] = -sn[j] * g[j];
-            g[j] = cs[j] * g[j];
+            if (flag != 0 || !std::isfinite(res)) { *reason = KNP_DIVERGED_NANORINF; stop = true; jd = j; break; }
             ++it;
             jd = j + 1;
-            res = std::fabs(g[j + 1]);
             if (res <= ttol) { *reason = (res <= atol) ? KNP_CONVERGED_ATOL : KNP_CONVERGED_RTOL; stop = true; break; }
             if (it >= max_it) { *reason = KNP_DIVERGED_ITS; stop = true; break; }
             if (res > dtol * res0) { *reason = KNP_DIVERGED_DTOL; stop = true; break; }
         }
         if (jd > 0) {
-            for (int i = jd - 1; i >= 0; --i) {
-                double s = g[i];
-                for (int k = i + 1; k < jd; ++k) s -= Hx(i, k) * y[k];
-                y[i] = s / Hx(i, i);
-            }
-            for (int i = 0; i < jd; ++i) ctx->h_red[i] = y[i];
-            HIPCHK(hipMemcpyAsync(ctx->d_y, ctx->h_red, jd * sizeof(double), hipMemcpyHostToDevice, st));
-            {
-                ProfScope ps(ctx, 1);
-                hipLaunchKernelGGL(k_lincomb, dim3(std::min(nblocks(n), 2048)), dim3(NT), 0, st, n, ldv, jd, ctx->d_V, ctx->d_y, x);
-            }
-            HIPCHK(hipStreamSynchronize(st));  // h_red is reused by the next reduction read-back
+            ProfScope ps(ctx, 1);
+            hipLaunchKernelGGL(k_gm_solve_y, dim3(1), dim3(64), 0, st, GL, jd, gm);
+            hipLaunchKernelGGL(k_lincomb, dim3(vec_blocks), dim3(NT), 0, st, n, ldv, jd, ctx->d_V, gm + GL.y(), x);
         }
         if (stop) break;
     }
@@ -3034,7 +3221,7 @@ int knp_profile_reset(knp_ctx* ctx) {
     CHECK_CTX(ctx);
     KCHK(prof_collect(ctx));
     for (int i = 0; i < KNP_NPROF; ++i) { ctx->prof_ms[i] = 0; ctx->prof_n[i] = 0; }
-    ctx->n_allreduce = ctx->n_halo = ctx->n_readback = 0;
+    ctx->n_allreduce = ctx->n_halo = ctx->n_readback = ctx->n_norm_fallback = 0;
     return KNP_OK;
 }
 int knp_get_stats(const knp_ctx* ctx, double* out) {
@@ -3045,6 +3232,7 @@ int knp_get_stats(const knp_ctx* ctx, double* out) {
     out[KNP_ST_HALO] = (double)ctx->n_halo;
     out[KNP_ST_READBACK] = (double)ctx->n_readback;
     out[KNP_ST_FUSED] = (double)(ctx->hier[0].fused + 2 * ctx->hier[1].fused);
+    out[KNP_ST_NORM_FALLBACK] = (double)ctx->n_norm_fallback;
     return KNP_OK;
 }
 
