@@ -177,8 +177,15 @@ class MixedDimensionalProblem(ABC):
         self.source_terms = config.get("source_terms", None)
         if self.source_terms not in (None, "ion_injection"):
             raise RuntimeError(f"Unknown source_terms '{self.source_terms}' (the reference knows 'ion_injection').")
-        self.point_evaluation = False
-        self.gamma_points = None
+        if "point_evaluation" in config:                     # mixed_dim_problem.py:277-287
+            pe = config["point_evaluation"]
+            self.point_evaluation = True
+            self.ics_points = np.array(pe["ics_points"], dtype=np.float64) * self.mesh_conversion_factor
+            self.ecs_points = np.array(pe["ecs_points"], dtype=np.float64) * self.mesh_conversion_factor
+            self.gamma_points = np.array(pe["gamma_points"], dtype=np.float64) * self.mesh_conversion_factor if "gamma_points" in pe else None
+        else:
+            self.point_evaluation = False
+            self.gamma_points = None
 
         if "stimulus" in config:
             try:

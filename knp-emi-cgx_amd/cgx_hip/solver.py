@@ -97,9 +97,9 @@ class SolverKNPEMI:
         self.save_mat = out.get("save_mat", False)
         if "save_interval" in out:
             self.save_interval = out["save_interval"]
-        if self.save_xdmfs or self.save_pngs or self.save_cpoints:
-            raise NotImplementedError("XDMF / PNG / checkpoint output is outside the native hot path (SURVEY 8f-4); "
-                                      "set save_xdmf/save_pngs/save_cpoints to False.")
+        if self.save_xdmfs:
+            raise NotImplementedError("XDMF/HDF5 output needs an HDF5 library (none in this environment); use save_cpoints "
+                                      "(.npz checkpoints of the nodal fields) and save_dat (.npy traces) instead.")
         self.out_file_prefix = problem.output_dir
         self.direct_solver = bool(solver_config["direct"])
         self.view_input = solver_config.get("view_ksp", False)
@@ -273,6 +273,11 @@ class SolverKNPEMI:
         self.iterations = []
         self.solve_time = []
         self.assembly_time = []
+        # traces, probe points, checkpoints (reference :96-99: init_png_savefile / init_checkpoint_file / init_data)
+        from .output import RunOutput
+        self.output = RunOutput(self) if (self.save_pngs or self.save_dat or self.save_cpoints or p.point_evaluation) else None
+        if self.output is not None:
+            self.output.record(0)
 
     # ---- reference :297-335
     def create_and_set_nullspace(self):
@@ -317,6 +322,8 @@ class SolverKNPEMI:
                 be.pc_setup(self._pc_kind)            # ksp.setOperators + ksp.setUp
                 self._sync()
                 setup_timer += self.comm.allreduce_max(time.perf_counter() - tic)
+                if self.view_input:
+                    self.view()
 
             if p.gating_variables:
                 tic = time.perf_counter()
@@ -364,6 +371,8 @@ class SolverKNPEMI:
                 raise RuntimeError(f"GMRES did not converge at step {i}: {_lib.REASONS.get(reason, reason)}")
 
             be.unpack()                                # x -> wh, phi_m_prev = phi_i - phi_e (reference :452-468)
+            if self.output is not None:
+                self.output.record(i)                  # reference :471-474 (checkpoint / trace / point evaluation)
             if p.MMS_test:
                 p.print_errors()                       # reference :500-501
 
@@ -373,6 +382,8 @@ class SolverKNPEMI:
                 self.print("Total assembly time:", sum(self.assembly_time))
                 self.print("Total solve time:", sum(self.solve_time))
                 self.print_info()
+                if self.save_pngs and self.output is not None:
+                    self.output.figures()
                 if self.save_dat:
                     self.export_data()
 
@@ -382,11 +393,28 @@ class SolverKNPEMI:
         return float(np.sqrt(a)), float(np.sqrt(b))
 
     def export_data(self):
-        """Timing / iteration arrays with the reference's file names (KNPEMIx_solver.py:862-866)."""
-        if self.comm.rank == 0:
+        """``.npy`` artefacts with the reference's file names (KNPEMIx_solver.py:833-866): membrane trace at the measurement
+        vertex, gating variables there, probe-point values, timings and iteration counts."""
+        if self.output is not None:
+            self.output.export()
+        elif self.comm.rank == 0:
             np.save(self.out_file_prefix + "assembly_time.npy", np.array(self.assembly_time))
             np.save(self.out_file_prefix + "solve_time.npy", np.array(self.solve_time))
             np.save(self.out_file_prefix + "iterations.npy", np.array(self.iterations))
+
+    def view(self):
+        """``--view 1`` / ``view_ksp``: what PETSc's -ksp_view reports for the reference (KNPEMIx_solver.py:285-288), for this solver."""
+        pr = self.print
+        be = self.backend
+        pr("KSP Object: type gmres (native), restart", self.gmres_restart, ", classical Gram-Schmidt, left preconditioning, "
+           "preconditioned-residual norm, one reduction per iteration")
+        pr(f"  tolerances: relative={self._rtol:g}, absolute=1e-50, divergence=1e5, maximum iterations={self.ksp_max_it}")
+        pr("  initial guess nonzero:", bool(self.nonzero_init_guess or self.direct_solver))
+        pr(f"PC Object: type {self.pc_type} -> native kind {self._pc_kind}", "(fused V(1,1) cycle)" if be.stats()["fused"] else "")
+        for k, h in enumerate(getattr(self, "hierarchies", []) or []):
+            if hasattr(h, "describe"):
+                pr(f"  hierarchy {k}:", h.describe())
+        pr(f"  linear system: {be.n_dof_global} unknowns, {be.nnz_global} stored entries, membrane programs: {be.lib.knp_jit_status(be.ctx).decode()}")
 
     # ---- reference :504-548
     def print_info(self):
