@@ -402,15 +402,15 @@ def cpu_baseline(case, args, solver, snap):
     o = mk(N, models=mdl)
     pre, post, deg = solver.amg_pre, solver.amg_post, solver.amg_cheby_degree
 
-    rnd = amg.fp32_stored if solver.amg_fp32 else (lambda h: h)     # operator values as the library stores them
-    fused = bool(solver.backend.stats()["fused"])                    # ... and the order in which its cycle evaluates them
+    fused = bool(solver.backend.stats()["fused"])                    # the order in which the library's cycle evaluates its operators
+    rnd = amg.fp32_stored if solver.amg_fp32 else (lambda h, **k: h)    # ... and their values as it stores them
 
     built = {}
 
     def fac(P, wrap=lambda h: h):      # hierarchies are built once (host setup, like ksp.setUp()) and shared by both CPU legs
         if not built:
             if pc == "btcc":
-                built["k"] = rnd(amg.build_hierarchy(amg.restrict_to_fields(P, (0, 1, 2)), theta=solver.amg_theta, coarse_size=solver.amg_coarse_size))
+                built["k"] = rnd(amg.build_hierarchy(amg.restrict_to_fields(P, (0, 1, 2)), theta=solver.amg_theta, coarse_size=solver.amg_coarse_size), coarse=fused)
                 built["p"] = rnd(amg.build_hierarchy(amg.restrict_to_fields(P, (3,)), theta=solver.amg_theta, coarse_size=solver.amg_coarse_size))
             else:
                 built["h"] = rnd(amg.build_hierarchy(P, theta=solver.amg_theta, coarse_size=solver.amg_coarse_size))

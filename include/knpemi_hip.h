@@ -266,8 +266,10 @@ int knp_amg_use_native_level0(knp_ctx* ctx, int32_t hier, int32_t mode);
  * Call before uploading a hierarchy. */
 int knp_amg_set_precision(knp_ctx* ctx, int32_t fp32_storage);
 /* optional: start ||B b|| of the next knp_gmres_solve(ctx, b, ...) on a side stream now (b complete, not to be modified until
- * the solve); it then overlaps whatever the caller enqueues next, typically knp_assemble_matrix.  No-op on distributed
- * contexts and before the first solve.  Any other call that touches the preconditioner or b joins / discards it. */
+ * the solve); it then overlaps whatever the caller enqueues next, typically knp_assemble_matrix.  No-op before the first solve
+ * and on distributed contexts whose exchanges go through the hooks (with the native peer-to-peer plans attached everywhere it
+ * runs: the exchange kernels are then ordered on the side stream on every rank).  Any other call that touches the
+ * preconditioner or b joins / discards it. */
 int knp_gmres_prepare(knp_ctx* ctx, const double* b);
 int knp_gmres_solve(knp_ctx* ctx, const double* b, double* x, double rtol, double atol, int32_t max_it,
                     int32_t restart, int32_t* its, double* rnorm, int32_t* reason);

@@ -272,9 +272,11 @@ def upload(lib, ctx, check, hier: Hierarchy, pre: int = 1, post: int = 1, cheby_
         check(lib.knp_amg_set_coarse(ctx, index, ci_.shape[0], fp(ci_)))
 
 
-def fp32_stored(h: Hierarchy) -> Hierarchy:
+def fp32_stored(h: Hierarchy, coarse: bool = False) -> Hierarchy:
     """The hierarchy as the library holds it with ``amg_fp32`` (default): level and transfer operator VALUES rounded to
-    fp32 (diagonals, vectors, arithmetic and the dense coarse inverse stay fp64).  For checkers that restate the V-cycle."""
+    fp32 (diagonals, vectors and arithmetic stay fp64).  ``coarse``: also the dense coarse inverse -- what the library does for
+    the ion-field hierarchy of the block-triangular preconditioner when its cycle runs fused (the potential hierarchy's and
+    the all-field hierarchy's coarse inverses stay fp64).  For checkers that restate the V-cycle."""
     import copy
 
     def rnd(M):
@@ -290,6 +292,8 @@ def fp32_stored(h: Hierarchy) -> Hierarchy:
         l2.A, l2.P, l2.R = rnd(lv.A), rnd(lv.P), rnd(lv.R)
         l2.S = rnd(getattr(lv, "S", None))
         out.levels.append(l2)
+    if coarse and h.coarse_inv is not None:
+        out.coarse_inv = h.coarse_inv.astype(np.float32).astype(np.float64)
     if out.levels:      # level 0 of the fused cycle applies Pt = A Dinv, computed in fp64 from the fp64 P and rounded once
         l0 = h.levels[0]
         out.levels[0].Pt = rnd((l0.A @ sp.diags(l0.dinv)).tocsr())

@@ -257,6 +257,12 @@ struct knp_ctx {
     int p2p_red = -1;    // all-reduce of the reduction slots
     bool hook_allreduce() const { return allreduce && p2p_red < 0; }
     int comm_rc = 0;     // first failure of a level exchange inside a preconditioner application
+    // interior / boundary split of the SpMV on A (multi-GPU): nodes without / with a ghost column; the native forward halo runs
+    // on stream3 next to the interior rows, the boundary rows follow the join
+    int n_int = 0, n_bnd = 0;
+    int32_t *d_nodes_int = nullptr, *d_nodes_bnd = nullptr;
+    hipStream_t stream3 = nullptr;
+    hipEvent_t ev_x = nullptr, ev_halo = nullptr;
     // side stream for ||B b|| of the next solve (knp_gmres_prepare)
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -266,6 +272,7 @@ struct knp_ctx {
     int64_t n_allreduce = 0, n_halo = 0, n_readback = 0;
     // profiling
     int prof_on = 0;
+    unsigned prof_tick = 0;   // the SpMV class binds events to every 4th launch only
     struct ProfRec { hipEvent_t a, b; int cls; };
     std::vector<ProfRec> prof_recs;
     double prof_ms[KNP_NPROF] = {0, 0, 0, 0, 0};

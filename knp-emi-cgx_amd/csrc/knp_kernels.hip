@@ -919,9 +919,10 @@ static int pick_lanes(double avg_nnz_per_row, int role = 0) {   // role 0 level 
     static const double scale_p = getenv("KNP_LANE_SCALE_P") ? atof(getenv("KNP_LANE_SCALE_P")) : 1.0;
     static const double scale_r = getenv("KNP_LANE_SCALE_R") ? atof(getenv("KNP_LANE_SCALE_R")) : 1.0;
     avg_nnz_per_row *= scale * (role == 1 ? scale_p : role == 2 ? scale_r : 1.0);
-    if (avg_nnz_per_row <= 6.0) return 2;
-    if (avg_nnz_per_row <= 12.0) return 4;
-    if (avg_nnz_per_row <= 28.0) return 8;
+    // row_dot4 keeps four entries per lane in flight: lanes = entries / 4, rounded up to a power of two
+    if (avg_nnz_per_row <= 8.0) return 2;
+    if (avg_nnz_per_row <= 16.0) return 4;
+    if (avg_nnz_per_row <= 32.0) return 8;
     if (avg_nnz_per_row <= 80.0) return 16;
     if (avg_nnz_per_row <= 192.0) return 32;
     return 64;
@@ -944,13 +945,18 @@ k_multi_dot(int n, int64_t ldv, int i0, int m, const double* __restrict__ V, con
     double ans = 0.0, aww = 0.0;
 #pragma unroll
     for (int g = 0; g < G; ++g) acc[g] = 0.0;
-    for (int e = blockIdx.x * NT + threadIdx.x; e < n; e += gridDim.x * NT) {
-        const double we = w[e];
-        if (NS && (e & 3) == 3) ans += we;
-        if (WW) aww += we * we;
+    // n is a multiple of 4 (4 unknowns per node): two entries per trip as one 16-byte load per vector
+    const int n2 = n >> 1;
+    for (int e2 = blockIdx.x * NT + threadIdx.x; e2 < n2; e2 += gridDim.x * NT) {
+        const double2 we = *reinterpret_cast<const double2*>(w + 2 * (size_t)e2);
+        if (NS && (e2 & 1)) ans += we.y;          // entry 2*e2+1 is a potential iff e2 is odd
+        if (WW) aww += we.x * we.x + we.y * we.y;
 #pragma unroll
         for (int g = 0; g < G; ++g)
-            if (i0 + g < m) acc[g] += V[(int64_t)(i0 + g) * ldv + e] * we;
+            if (i0 + g < m) {
+                const double2 v = *reinterpret_cast<const double2*>(V + (int64_t)(i0 + g) * ldv + 2 * (size_t)e2);
+                acc[g] += v.x * we.x + v.y * we.y;
+            }
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -1116,11 +1122,17 @@ k_update_scale(int n, int64_t ldv, int m, const double* __restrict__ V, const do
                const double* __restrict__ st, double ns_scale, double* __restrict__ out) {
     const double inv = st[1] == 0.0 ? 1.0 / sqrt(st[0]) : 1.0;
     const double mean = ns_scale != 0.0 ? h[m] * ns_scale : 0.0;
-    for (int e = blockIdx.x * NT + threadIdx.x; e < n; e += gridDim.x * NT) {
-        double we = w[e];
-        if ((e & 3) == 3) we -= mean;
-        for (int i = 0; i < m; ++i) we -= h[i] * V[(int64_t)i * ldv + e];
-        out[e] = we * inv;
+    const int n2 = n >> 1;
+    for (int e2 = blockIdx.x * NT + threadIdx.x; e2 < n2; e2 += gridDim.x * NT) {
+        double2 we = *reinterpret_cast<const double2*>(w + 2 * (size_t)e2);
+        if (e2 & 1) we.y -= mean;
+        for (int i = 0; i < m; ++i) {
+            const double2 v = *reinterpret_cast<const double2*>(V + (int64_t)i * ldv + 2 * (size_t)e2);
+            const double hi = h[i];
+            we.x -= hi * v.x;
+            we.y -= hi * v.y;
+        }
+        *reinterpret_cast<double2*>(out + 2 * (size_t)e2) = make_double2(we.x * inv, we.y * inv);
     }
 }
 __global__ void __launch_bounds__(NT) k_scale_inplace_rsqrt(int n, const double* __restrict__ nrm2, double* __restrict__ v) {
@@ -1406,6 +1418,25 @@ __global__ void __launch_bounds__(NT) k_dense_matvec(int n, const VT* __restrict
                 const double2 a = m2[k];
                 const double2 xa = x2[k];
                 s0 += a.x * xa.x + a.y * xa.y;
+            }
+            s = s0 + s1;
+        } else if (sizeof(VT) == 4 && (n & 3) == 0) {
+            // fp32 storage: 16-B loads of four matrix entries, two 16-B loads of x, two trips in flight
+            const float4* m4 = reinterpret_cast<const float4*>(m);
+            const double2* x2 = reinterpret_cast<const double2*>(x);
+            const int n4 = n >> 2;
+            double s0 = 0.0, s1 = 0.0;
+            int k = lane;
+            for (; k + 64 < n4; k += 128) {
+                const float4 a = m4[k], b = m4[k + 64];
+                const double2 xa = x2[2 * k], xb = x2[2 * k + 1], xc = x2[2 * (k + 64)], xd = x2[2 * (k + 64) + 1];
+                s0 += (double)a.x * xa.x + (double)a.y * xa.y + (double)a.z * xb.x + (double)a.w * xb.y;
+                s1 += (double)b.x * xc.x + (double)b.y * xc.y + (double)b.z * xd.x + (double)b.w * xd.y;
+            }
+            if (k < n4) {
+                const float4 a = m4[k];
+                const double2 xa = x2[2 * k], xb = x2[2 * k + 1];
+                s0 += (double)a.x * xa.x + (double)a.y * xa.y + (double)a.z * xb.x + (double)a.w * xb.y;
             }
             s = s0 + s1;
         } else {
@@ -1735,6 +1766,23 @@ int knp_create(knp_ctx** out, const knp_mesh_desc* mesh) {
         const char* ep = getenv("KNP_PC_GROUP");
         if (ep && atoi(ep) > 0) ctx->pc_group = atoi(ep);
     }
+    if (g.n_nodes > g.n_nodes_owned) {   // multi-GPU: rows that touch a ghost column wait for the halo, the others do not
+        std::vector<int32_t> li, lb;
+        const int no = g.n_nodes_owned;
+        for (int n = 0; n < no; ++n) {
+            bool bnd = false;
+            for (int pq = g.pair_ptr[n]; pq < g.pair_ptr[n + 1] && !bnd; ++pq) bnd = g.pair_col[pq] >= no;
+            const int A = g.node_gv[n];
+            if (A >= 0 && !bnd) {
+                const std::vector<int32_t>& gx = g.node_side[n] ? g.gx_e : g.gx_i;
+                for (int sgp = g.gptr[A]; sgp < g.gptr[A + 1] && !bnd; ++sgp) bnd = gx[sgp] >= no;
+            }
+            (bnd ? lb : li).push_back(n);
+        }
+        ctx->n_int = (int)li.size(); ctx->n_bnd = (int)lb.size();
+        KCHK(dev_upload(ctx, &ctx->d_nodes_int, li));
+        KCHK(dev_upload(ctx, &ctx->d_nodes_bnd, lb));
+    }
     // free the big host arrays that are no longer needed (pattern kept for export)
     std::vector<int32_t>().swap(g.contrib_cell);
     std::vector<double>().swap(g.contrib_k);
@@ -1745,6 +1793,8 @@ int knp_destroy(knp_ctx* ctx) {
     if (!ctx) return KNP_OK;
     (void)hipDeviceSynchronize();
     if (ctx->stream2) { (void)hipEventDestroy(ctx->ev_fork); (void)hipEventDestroy(ctx->ev_join); (void)hipStreamDestroy(ctx->stream2); }
+    if (ctx->stream3) { (void)hipEventDestroy(ctx->ev_x); (void)hipEventDestroy(ctx->ev_halo); (void)hipStreamDestroy(ctx->stream3); }
+    dev_free(ctx->d_nodes_int); dev_free(ctx->d_nodes_bnd);
     knp_p2p_free(ctx);
     knp_jit_release(ctx);
     for (auto& r : ctx->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -2294,14 +2344,39 @@ static int ensure_work(knp_ctx* ctx, int restart) {
 }
 
 static int spmv_A(knp_ctx* ctx, double* x, const double* b, double* y, bool residual) {
-    KCHK(halo_update(ctx, x));
     const KnpHostGraph& g = ctx->g;
     hipEvent_t ea = nullptr, eb = nullptr;
-    if (ctx->prof_on & 1) {   // class 0: events tied to the kernel's begin / end
+    if ((ctx->prof_on & 1) && (ctx->prof_tick++ & 3) == 0) {   // class 0: events tied to the kernel's begin / end, every 4th launch
         if (hipEventCreate(&ea) != hipSuccess || hipEventCreate(&eb) != hipSuccess) { ea = eb = nullptr; }
     }
-    if (residual) launch_spmv_node<1>(ctx, g.n_nodes_owned, nullptr, x, b, y, ea, eb);
-    else launch_spmv_node<0>(ctx, g.n_nodes_owned, nullptr, x, b, y, ea, eb);
+    static const bool no_split = getenv("KNP_SPMV_SPLIT") && atoi(getenv("KNP_SPMV_SPLIT")) == 0;
+    if (ctx->p2p_fine >= 0 && ctx->n_bnd > 0 && ctx->n_int > 0 && !no_split) {
+        // native halo on its own stream while the interior rows run; the boundary rows follow the join ("overlap with
+        // interior-row SpMV, then boundary-row SpMV").  The halo kernel occupies at most one block per CU while it waits.
+        if (!ctx->stream3) {
+            HIPCHK(hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&ctx->ev_x, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&ctx->ev_halo, hipEventDisableTiming));
+        }
+        ++ctx->n_halo;
+        HIPCHK(hipEventRecord(ctx->ev_x, ctx->stream));
+        HIPCHK(hipStreamWaitEvent(ctx->stream3, ctx->ev_x, 0));
+        hipStream_t main_stream = ctx->stream;
+        ctx->stream = ctx->stream3;
+        const int rc = knp_p2p_halo_forward(ctx, ctx->p2p_fine, x);
+        ctx->stream = main_stream;
+        KCHK(rc);
+        HIPCHK(hipEventRecord(ctx->ev_halo, ctx->stream3));
+        if (residual) launch_spmv_node<1>(ctx, ctx->n_int, ctx->d_nodes_int, x, b, y, ea, nullptr);
+        else launch_spmv_node<0>(ctx, ctx->n_int, ctx->d_nodes_int, x, b, y, ea, nullptr);
+        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_halo, 0));
+        if (residual) launch_spmv_node<1>(ctx, ctx->n_bnd, ctx->d_nodes_bnd, x, b, y, nullptr, eb);
+        else launch_spmv_node<0>(ctx, ctx->n_bnd, ctx->d_nodes_bnd, x, b, y, nullptr, eb);
+    } else {
+        KCHK(halo_update(ctx, x));
+        if (residual) launch_spmv_node<1>(ctx, g.n_nodes_owned, nullptr, x, b, y, ea, eb);
+        else launch_spmv_node<0>(ctx, g.n_nodes_owned, nullptr, x, b, y, ea, eb);
+    }
     if (ea && eb) ctx->prof_recs.push_back({ea, eb, 0});
     HIPCHK(hipGetLastError());
     return KNP_OK;
@@ -2522,6 +2597,14 @@ static int build_fused_data(knp_ctx* ctx, KnpAmgHier& H) {
         if (phi) HIPCHK(hipMalloc((void**)&H.pt_phi, std::max<int64_t>(np, 1) * sizeof(double)));
         else HIPCHK(hipMalloc((void**)&H.pt, std::max<int64_t>(4 * np, 1) * sizeof(double)));
         hipLaunchKernelGGL((k_build_pt<double>), dim3(nblk), dim3(NT), 0, ctx->stream, np, ctx->d_pair_col, ctx->d_p_vals, L.inv_diag, H.pt, H.pt_phi);
+    }
+    // The dense coarse inverse of the ION hierarchy (well conditioned: M + dt D K) is stored in fp32 like the other operators
+    // of the mixed-precision preconditioner; the potential hierarchy's stays fp64 (nearly singular, cond ~1e8).
+    dev_free(H.cinv_f);
+    if (H.native0 == 2 && ctx->amg_fp32 && H.nc > 0 && H.cinv) {
+        const int64_t nn2 = (int64_t)H.nc * H.nc;
+        HIPCHK(hipMalloc((void**)&H.cinv_f, nn2 * sizeof(float)));
+        hipLaunchKernelGGL(k_to_float, dim3(std::min<int64_t>(nblocks(nn2), 4096)), dim3(NT), 0, ctx->stream, nn2, H.cinv, H.cinv_f);
     }
     if (phi) {
         const int nn = ctx->g.n_nodes_owned;
@@ -2759,7 +2842,8 @@ static void amg_cycle_fused(knp_ctx* ctx, KnpAmgHier& H, const double* b, double
         if (l + 1 == nl - 1) {   // coarsest: b_c = R r ; x_c = Cinv b_c
             if (L.R_vf) launch_spmv_t<0, 0, float>(st, L.R_lanes, nc, L.R_rp, Rci, L.R_vf, L.r, nullptr, C.b);
             else launch_spmv_t<0, 0, double>(st, L.R_lanes, nc, L.R_rp, Rci, L.R_v, L.r, nullptr, C.b);
-            hipLaunchKernelGGL((k_dense_matvec<double>), dim3(nblocks((int64_t)H.nc * 64)), dim3(NT), 0, st, H.nc, H.cinv, C.b, C.x);
+            if (H.cinv_f) hipLaunchKernelGGL((k_dense_matvec<float>), dim3(nblocks((int64_t)H.nc * 64)), dim3(NT), 0, st, H.nc, H.cinv_f, C.b, C.x);
+            else hipLaunchKernelGGL((k_dense_matvec<double>), dim3(nblocks((int64_t)H.nc * 64)), dim3(NT), 0, st, H.nc, H.cinv, C.b, C.x);
         } else {                 // b_c = R r ; x_c = c Dinv b_c (first Chebyshev step, fused) ; r_c = b_c - A_c x_c
             const double cc = cheb_c(C);
             if (L.R_vf) launch_restrict_first_t<float>(st, L.R_lanes, nc, L.R_rp, Rci, L.R_vf, L.r, C.b, cc, C.inv_diag, C.d, C.x);
@@ -2959,6 +3043,18 @@ static void side_discard(knp_ctx* ctx) {   // any call that could touch what the
     }
 }
 
+static bool exchanges_all_native(const knp_ctx* ctx) {
+    if (!ctx->p2p || ctx->p2p_fine < 0 || ctx->p2p_red < 0 || ctx->defl_m > 0) return false;
+    const int nh = ctx->pc_kind == KNP_PC_AMG ? 1 : ctx->pc_kind == KNP_PC_AMG_BT ? 2 : 0;
+    for (int h = 0; h < nh; ++h)
+        for (int l = 0; l < ctx->hier[h].levels; ++l) {
+            const KnpAmgLevel& L = ctx->hier[h].lv[l];
+            if (L.dist && L.p2p_halo < 0) return false;
+            if (L.repl_n > 0 && L.p2p_repl < 0) return false;
+        }
+    return true;
+}
+
 int knp_gmres_prepare(knp_ctx* ctx, const double* b) {
     CHECK_CTX(ctx);
     if (!b) return KNP_E_ARG;
@@ -2968,7 +3064,11 @@ int knp_gmres_prepare(knp_ctx* ctx, const double* b) {
     const bool off = getenv("KNP_NO_PREPARE") != nullptr;
     // vertex-block Jacobi takes its blocks from the matrix that knp_assemble_matrix is about to rewrite: nothing to overlap
     if (ctx->pc_kind == KNP_PC_VBJACOBI) return KNP_OK;
-    if (off || ctx->halo || ctx->allreduce || ctx->level_comm || ctx->p2p || ctx->gm_restart <= 0 || (ctx->prof_on & ~1)) return KNP_OK;
+    // Distributed contexts: legal when EVERY exchange of the preconditioner runs in the library (native peer-to-peer plans):
+    // those kernels are launched on ctx->stream, i.e. on the side stream here, in the same order on every rank, and the main
+    // stream does no exchange until the solve joins.  With torch.distributed hooks (ordered on torch's stream) it stays a no-op.
+    if (off || ctx->gm_restart <= 0 || (ctx->prof_on & ~1)) return KNP_OK;
+    if ((ctx->halo || ctx->allreduce || ctx->level_comm || ctx->p2p) && !exchanges_all_native(ctx)) return KNP_OK;
     if (!ctx->stream2) {
         HIPCHK(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));

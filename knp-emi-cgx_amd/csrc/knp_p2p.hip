@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -77,8 +78,12 @@ __device__ __forceinline__ void p2p_publish(const P2PSend& a, unsigned int* coun
 // Phase 1 writes this rank's data into the peers' mailboxes and (last block) publishes the sequence number; phase 2 waits
 // for the peers' numbers and consumes the own mailbox.  A block may reach phase 2 before the own publish happened: it then
 // only waits for PEERS, whose publish depends on their own phase 1 alone, so there is no circular wait as long as every
-// block of the grid is resident (grids are capped at P2P_MAX_BLOCKS, far below what one GPU holds).
-#define P2P_MAX_BLOCKS 64
+// block of the grid is resident.  The grid is sized from the message (one block per 1 K entries; a 3-4 MB halo of a
+// 10^7-DoF subdomain gets the full 256 instead of the 64 blocks of the first version) and capped at
+// one block per CU (256): with up to 6 ranks sharing one GPU (the test boxes) that is 6 blocks per CU, within the 8 that
+// 256-thread blocks of this register footprint are admitted at, so every block of every rank is resident at the same time.
+#define P2P_MAX_BLOCKS 256
+#define P2P_ENTRIES_PER_BLOCK 1024
 
 __device__ __forceinline__ void p2p_wait_all(const P2PWait& w, int64_t seq, int64_t timeout, int* err, const int* d_err) {
     if (threadIdx.x == 0)
@@ -149,7 +154,10 @@ __global__ void __launch_bounds__(P2P_NT) k_p2p_allreduce(P2PSend a, P2PWait w, 
     }
 }
 
-static inline int p2p_blocks(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + P2P_NT - 1) / P2P_NT, P2P_MAX_BLOCKS)); }
+static inline int p2p_blocks(int64_t n) {
+    static const int cap = getenv("KNP_P2P_MAX_BLOCKS") ? std::max(1, atoi(getenv("KNP_P2P_MAX_BLOCKS"))) : P2P_MAX_BLOCKS;
+    return (int)std::max<int64_t>(1, std::min<int64_t>((n + P2P_ENTRIES_PER_BLOCK - 1) / P2P_ENTRIES_PER_BLOCK, cap));
+}
 static inline int64_t* flag_at(char* box, int which, int size, int r) {   // which: 0 forward / all-reduce, 1 reverse
     return reinterpret_cast<int64_t*>(box + ((size_t)which * size + r) * P2P_FLAG_STRIDE);
 }

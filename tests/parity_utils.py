@@ -92,12 +92,12 @@ def oracle_gmres_same_algorithm(kind, N, steps, pc, rtol, solver, models="ci"):
     from cgx_hip import amg
     o = make_oracle(N, kind, models)
     pre, post, deg = solver.amg_pre, solver.amg_post, solver.amg_cheby_degree
-    rnd = fp32_stored if solver.amg_fp32 else (lambda h: h)
     fused = bool(solver.backend.stats()["fused"])
+    rnd = fp32_stored if solver.amg_fp32 else (lambda h, **k: h)
 
     def fac(P):
         if pc == "btcc":
-            hk = rnd(amg.build_hierarchy(amg.restrict_to_fields(P, (0, 1, 2)), theta=solver.amg_theta, coarse_size=solver.amg_coarse_size))
+            hk = rnd(amg.build_hierarchy(amg.restrict_to_fields(P, (0, 1, 2)), theta=solver.amg_theta, coarse_size=solver.amg_coarse_size), coarse=fused)
             hp = rnd(amg.build_hierarchy(amg.restrict_to_fields(P, (3,)), theta=solver.amg_theta, coarse_size=solver.amg_coarse_size))
             return K.pc_btcc(o, hk, hp, pre, post, deg, fused=fused)
         h = rnd(amg.build_hierarchy(P, theta=solver.amg_theta, coarse_size=solver.amg_coarse_size))

@@ -201,7 +201,7 @@ def test_btcc_iterates_match_oracle(N, kind, steps, fp32):
     s = run_native(cfg)
     hk, hp = s.hierarchies
     if fp32:
-        hk, hp = fp32_stored(hk), fp32_stored(hp)
+        hk, hp = fp32_stored(hk, coarse=bool(s.backend.stats()["fused"])), fp32_stored(hp)
     assert len(hk.levels) >= 2 and len(hp.levels) >= 2
     o = make_oracle(N, kind)
     xo, its = o.run(steps, solver="gmres", rtol=1e-9,
