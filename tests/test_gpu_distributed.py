@@ -153,3 +153,77 @@ def test_p2p_wait_times_out_instead_of_hanging():
     rc, secs, msg = res[0]
     assert rc != 0 and "timed out" in msg
     assert 1.5 <= secs <= 20.0
+
+
+def _big_halo_worker(rank, size, port, q):
+    try:
+        for p in (os.path.join(ROOT, "knp-emi-cgx_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+            sys.path.insert(0, p)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ["KNP_COMM"] = "p2p"
+        os.environ["KNP_P2P_TIMEOUT"] = "20"
+        import ctypes as C
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=size)
+        from cgx_hip.dist_amg import LevelHalo
+        from parity_utils import ci_config, make_problem
+        p = make_problem(ci_config(N=8, steps=1))
+        be = p.create_backend()
+        assert be.p2p_on
+        # ring of 4 ranks, every rank holds 140 000 ghost copies of each of its two neighbours' entries: 2 x 1.12 MB forward,
+        # the same reverse -- the size of the halo of a 10^7-DoF subdomain (3-4 MB per SpMV), far beyond the 64 x 256
+        # entries one wave of the old 64-block grid covered
+        n_own, n_g = 300_000, 140_000
+        start = rank * n_own
+        nbrs = sorted({(rank + 1) % size, (rank - 1) % size})
+        rng = np.random.default_rng(10 + rank)
+        gid, own = [], []
+        for r in nbrs:
+            ids = np.sort(rng.choice(n_own, n_g, replace=False)) + r * n_own
+            gid.append(ids)
+            own.append(np.full(n_g, r))
+        gid, own = np.concatenate(gid), np.concatenate(own)
+        halo = LevelHalo(p.comm, n_own, gid, own, start, be.device)
+        plan = be._p2p_halo_plan(halo)            # collective; self-tested against the torch.distributed exchange (8 repetitions,
+        ok_halo = plan is not None                #  forward bit-exact, reverse sums to 1e-13) -- through knp_p2p_test_halo
+        red = be._p2p_allreduce_plan(32)          # 32-value all-reduce, bit-identical on all ranks -- through knp_p2p_test_allreduce
+        ok_red = red is not None
+        # once more by hand with a known answer: ghost g of owner r must read 1e6 r + local index
+        x = torch.zeros(halo.n_loc, dtype=torch.float64, device=be.device)
+        x[:n_own] = torch.arange(n_own, dtype=torch.float64, device=be.device) + 1e6 * rank
+        rc = be.lib.knp_p2p_test_halo(be.ctx, plan, C.c_void_p(x.data_ptr()), 0) if ok_halo else -1
+        expect = torch.as_tensor((gid - own * n_own) + 1e6 * own, dtype=torch.float64, device=be.device)
+        exact = bool(torch.equal(x[n_own:], expect))
+        v = torch.arange(32, dtype=torch.float64, device=be.device) * (rank + 1)
+        rc2 = be.lib.knp_p2p_test_allreduce(be.ctx, red, C.c_void_p(v.data_ptr()), 32) if ok_red else -1
+        exact2 = bool(torch.equal(v, torch.arange(32, dtype=torch.float64, device=be.device) * (size * (size + 1) / 2)))
+        dist.barrier()
+        q.put((rank, "ok", ok_halo, ok_red, rc, exact, rc2, exact2, int(halo.n_loc - n_own) * 8))
+        dist.destroy_process_group()
+    except Exception:      # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+def test_native_exchange_moves_a_multi_megabyte_halo_over_four_ranks():
+    """The native peer-to-peer exchange at the message sizes of the 10^7-DoF-per-GPU point: > 2 MB of ghost values per
+    exchange over 4 ranks (grid sized from the message, still fully resident), and a 32-value all-reduce."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_big_halo_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(4)]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[1] == "ok", f"rank {r[0]}:\n{r[1]}"
+        assert r[2] and r[3], "self-test of the native exchange failed"
+        assert r[4] == 0 and r[5], "forward halo wrong"
+        assert r[6] == 0 and r[7], "all-reduce wrong"
+        assert r[8] >= 2_000_000
