@@ -10,7 +10,7 @@ builds ONE hierarchy for the whole distributed matrix:
   * aggregates never cross a rank boundary (aggregation runs on the owned-owned block), but the smoothed
     prolongator, the Galerkin products and the level operators include all couplings across ranks;
   * the rows of the prolongator that belong to ghost nodes and the off-rank rows of the coarse operator are
-    exchanged once at setup (object collectives, setup only);
+    exchanged once at setup (packed tensors through ``all_to_all_single``: parallel.exchange_arrays);
   * at apply time a level needs: a forward halo before each operator application, a reverse (accumulating)
     halo after the restriction, and -- below ``replicate_below`` global unknowns -- an all-reduce that
     replicates the coarse right-hand side so that every rank runs the small remaining hierarchy redundantly.
@@ -25,6 +25,7 @@ import torch
 import torch.distributed as dist
 
 from . import amg
+from .parallel import exchange_arrays
 
 
 class _Accel:
@@ -100,11 +101,9 @@ class LevelHalo:
             sel = np.nonzero(ghost_owner == o)[0]
             req[int(o)] = ghost_gid[sel]
             recv_idx[int(o)] = self.n_own + sel
-        gathered = comm.all_gather_object(req)
-        for r, rq in enumerate(gathered):
-            if r == comm.rank or comm.rank not in rq:
-                continue
-            loc = np.asarray(rq[comm.rank], dtype=np.int64) - own_gid_start
+        got = exchange_arrays(comm, {o: [np.asarray(g, dtype=np.int64)] for o, g in req.items()})
+        for r, (gids,) in got.items():
+            loc = np.asarray(gids, dtype=np.int64) - own_gid_start
             assert (loc >= 0).all() and (loc < self.n_own).all(), "halo request for a row this rank does not own"
             send_idx[r] = loc
         self._finish(send_idx, recv_idx)
@@ -240,12 +239,11 @@ def build_distributed_hierarchy(comm, P_loc: sp.csr_matrix, halo0: LevelHalo, ow
         out = {}
         for r in np.unique(row_owner[~mine]):
             sel = row_owner == r
-            out[int(r)] = (C.row[sel], C.col[sel], C.data[sel])
-        gathered = comm.all_gather_object(out)
+            out[int(r)] = [C.row[sel].astype(np.int64), C.col[sel].astype(np.int64), C.data[sel]]
+        got = exchange_arrays(comm, out)                 # packed tensors, all_to_all_single
         rr, cc, vv = [C.row[mine]], [C.col[mine]], [C.data[mine]]
-        for r, o in enumerate(gathered):
-            if r != rank and rank in o:
-                rr.append(o[rank][0]); cc.append(o[rank][1]); vv.append(o[rank][2])
+        for r in sorted(got):
+            rr.append(got[r][0]); cc.append(got[r][1]); vv.append(got[r][2])
         rr, cc, vv = np.concatenate(rr), np.concatenate(cc), np.concatenate(vv)
         Ac_glob = sp.coo_matrix((vv, (rr - offs[rank], cc)), shape=(int(nagg), nagg_glob)).tocsr()   # my rows, global cols
         Ac_glob.sum_duplicates()
@@ -265,7 +263,10 @@ def build_distributed_hierarchy(comm, P_loc: sp.csr_matrix, halo0: LevelHalo, ow
             L.n_coarse_own, L.n_coarse_loc = int(nagg), nagg_glob
             L.repl_n, L.repl_offset = nagg_glob, int(offs[rank])
             levels.append(L)
-            parts = comm.all_gather_object((Ac_glob.indptr, Ac_glob.indices, Ac_glob.data))
+            mine_blk = [Ac_glob.indptr.astype(np.int64), Ac_glob.indices.astype(np.int64), Ac_glob.data]
+            got = exchange_arrays(comm, {r: mine_blk for r in range(size) if r != rank})
+            got[rank] = mine_blk
+            parts = [got[r] if r in got else [np.zeros(1, np.int64), np.zeros(0, np.int64), np.zeros(0)] for r in range(size)]
             mats = [sp.csr_matrix((d, i, p), shape=(len(p) - 1, nagg_glob)) for (p, i, d) in parts]
             A_rep = sp.vstack(mats).tocsr()
             tail = amg.build_hierarchy(A_rep, theta=theta * 0.25 ** len(levels), coarse_size=coarse_size)
@@ -323,20 +324,13 @@ def _dist_lambda_max(comm, A, dinv, halo, iters=20, seed=1, matvec=None):
 
 
 def _exchange_rows(comm, halo: LevelHalo, M_own: sp.csr_matrix, n_ghost: int, n_cols: int) -> sp.csr_matrix:
-    """rows of a distributed sparse matrix for this rank's ghost rows (setup-time object exchange)"""
-    if n_ghost == 0:
-        return sp.csr_matrix((0, n_cols))
+    """rows of a distributed sparse matrix for this rank's ghost rows (setup-time exchange; collective)"""
     out = {}
     for r, ix in halo.send_idx.items():
         sub = M_own[ix.cpu().numpy()]
-        out[int(r)] = (sub.indptr, sub.indices, sub.data)
-    gathered = comm.all_gather_object(out)
-    G = sp.lil_matrix((n_ghost, n_cols))
-    blocks = {}
-    for r, o in enumerate(gathered):
-        if r != comm.rank and comm.rank in o:
-            p, i, d = o[comm.rank]
-            blocks[r] = sp.csr_matrix((d, i, p), shape=(len(p) - 1, n_cols))
+        out[int(r)] = [sub.indptr.astype(np.int64), sub.indices.astype(np.int64), sub.data]
+    got = exchange_arrays(comm, out)                     # packed tensors, all_to_all_single
+    blocks = {r: sp.csr_matrix((d, i, p), shape=(len(p) - 1, n_cols)) for r, (p, i, d) in got.items()}
     rows = np.zeros(n_ghost, dtype=object)
     coo_r, coo_c, coo_v = [], [], []
     for r, blk in blocks.items():

@@ -312,14 +312,13 @@ class HaloPlan:
                 nodes = np.stack([node_i[sel], node_e[sel]], axis=1).ravel()
                 nodes = nodes[np.stack([has_i, has_e], axis=1).ravel()]
                 recv_idx[int(o)] = (4 * nodes[:, None] + np.arange(4)[None, :]).ravel()
-            gathered = comm.all_gather_object(requests)
+            got = exchange_arrays(comm, {o: [np.asarray(g, dtype=np.int64), hi.astype(np.int64), he.astype(np.int64)]
+                                         for o, (g, hi, he) in requests.items()})
             owned_gid = lm.l2g[:nvo]
             order = np.argsort(owned_gid, kind="stable")
             sorted_gid = owned_gid[order]
-            for r, req in enumerate(gathered):
-                if r == comm.rank or comm.rank not in req:
-                    continue
-                gids, has_i, has_e = req[comm.rank]
+            for r in sorted(got):
+                gids, has_i, has_e = got[r][0], got[r][1].astype(bool), got[r][2].astype(bool)
                 pos = np.searchsorted(sorted_gid, gids)
                 assert (pos < len(sorted_gid)).all() and (sorted_gid[pos] == gids).all(), "halo request for a vertex this rank does not own"
                 lv = order[pos]
@@ -338,6 +337,56 @@ class HaloPlan:
     def exchange(self, x: torch.Tensor):
         """Fill the ghost entries of the local vector x (owned part first) from their owners."""
         self._h.forward(x)
+
+
+def exchange_arrays(comm: Comm, out: dict) -> dict:
+    """Point-to-point exchange of NumPy arrays at setup time: ``out[dest] = [array, ...]`` (int or float, 1-D) -> ``{src: [...]}``.
+    Packed: every message becomes one float64 buffer ``[n_arrays, (kind, length)..., data...]`` (integers are exact in float64
+    below 2^53) and the whole exchange is TWO ``all_to_all_single`` calls (sizes, payload) -- no pickling, and nobody receives
+    what is not addressed to it (the object all-gather this replaces shipped every message to every rank).  Collective."""
+    size, rank = comm.size, comm.rank
+    if size == 1:
+        return {}
+    dev = torch.device("cuda") if comm.backend == "nccl" else torch.device("cpu")
+    bufs = []
+    for r in range(size):
+        arrs = out.get(r, None) if r != rank else None
+        if not arrs:
+            bufs.append(np.zeros(0))
+            continue
+        head = [float(len(arrs))]
+        for a in arrs:
+            a = np.asarray(a)
+            assert a.ndim == 1
+            head += [0.0 if np.issubdtype(a.dtype, np.integer) else 1.0, float(a.size)]
+        bufs.append(np.concatenate([np.asarray(head)] + [np.asarray(a, dtype=np.float64) for a in arrs]))
+    in_splits = [int(b.size) for b in bufs]
+    t_in = torch.tensor(in_splits, dtype=torch.int64, device=dev)
+    t_out = torch.empty(size, dtype=torch.int64, device=dev)
+    dist.all_to_all_single(t_out, t_in)
+    out_splits = [int(v) for v in t_out.cpu().tolist()]
+    send = torch.as_tensor(np.concatenate(bufs) if sum(in_splits) else np.zeros(0), dtype=torch.float64, device=dev)
+    recv = torch.empty(sum(out_splits), dtype=torch.float64, device=dev)
+    dist.all_to_all_single(recv, send, out_splits, in_splits)
+    recv = recv.cpu().numpy()
+    res, pos = {}, 0
+    for r in range(size):
+        n = out_splits[r]
+        if n == 0:
+            continue
+        b = recv[pos:pos + n]
+        pos += n
+        na = int(b[0])
+        kinds = b[1:1 + 2 * na:2]
+        lens = b[2:2 + 2 * na:2].astype(np.int64)
+        off = 1 + 2 * na
+        arrs = []
+        for k in range(na):
+            a = b[off:off + lens[k]]
+            off += lens[k]
+            arrs.append(np.rint(a).astype(np.int64) if kinds[k] == 0.0 else a.copy())
+        res[r] = arrs
+    return res
 
 
 def all_reduce_sum_(t: torch.Tensor, comm: Comm):

@@ -134,3 +134,73 @@ def test_two_rank_halo_and_reductions(kind, N, generator):
         p.join(timeout=60)
     for r, msg in res:
         assert msg == "ok", f"rank {r}:\n{msg}"
+
+
+def _setup_worker(rank, size, port, q):
+    try:
+        for p in (os.path.join(ROOT, "knp-emi-cgx_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+            sys.path.insert(0, p)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=size)
+        import scipy.sparse as sp
+        from cgx_hip import amg, dist_amg
+        from cgx_hip.parallel import Comm, exchange_arrays
+        comm = Comm()
+        # ---- packed point-to-point exchange: ints and floats, empty and missing messages
+        out = {}
+        for r in range(size):
+            if r != rank and (rank + r) % 2 == 1:
+                out[r] = [np.arange(rank * 10, rank * 10 + r + 3, dtype=np.int64), np.linspace(0, 1, r + 2) + rank, np.zeros(0)]
+        got = exchange_arrays(comm, out)
+        for r in range(size):
+            if r != rank and (rank + r) % 2 == 1:
+                a, b, c = got[r]
+                assert a.dtype == np.int64 and np.array_equal(a, np.arange(r * 10, r * 10 + rank + 3))
+                assert np.allclose(b, np.linspace(0, 1, rank + 2) + r) and c.size == 0
+            else:
+                assert r not in got
+        # ---- distributed hierarchy of a 2D Laplacian split by rows: every exchange of the setup goes through exchange_arrays
+        n1 = 24
+        T = sp.diags([-1, 2.0001, -1], [-1, 0, 1], shape=(n1, n1))
+        A = (sp.kron(sp.identity(n1), T) + sp.kron(T, sp.identity(n1))).tocsr()
+        n = A.shape[0]
+        lo, hi = rank * n // size, (rank + 1) * n // size
+        rows = A[lo:hi].tocsr()
+        cols = np.unique(rows.indices)
+        ghost = cols[(cols < lo) | (cols >= hi)]
+        cmap = np.full(n, -1)
+        cmap[lo:hi] = np.arange(hi - lo)
+        cmap[ghost] = (hi - lo) + np.arange(len(ghost))
+        Aloc = sp.csr_matrix((rows.data, cmap[rows.indices], rows.indptr), shape=(hi - lo, hi - lo + len(ghost)))
+        owner = np.minimum(ghost * size // n, size - 1)
+        owner = np.array([r for g in ghost for r in range(size) if r * n // size <= g < (r + 1) * n // size])
+        halo = dist_amg.LevelHalo(comm, hi - lo, ghost, owner, lo, "cpu")
+        levels, tail = dist_amg.build_distributed_hierarchy(comm, Aloc, halo, lo, ghost, owner, coarse_size=20, replicate_below=60, device="cpu")
+        desc = dist_amg.describe(levels, tail, comm)
+        # the replicated tail is the same matrix on every rank, and its first operator is the Galerkin product of the serial setup's size
+        sig = (desc["rows"], [round(float(abs(lv.A).sum()), 9) for lv in tail.levels]) if tail is not None else (desc["rows"], [])
+        sigs = comm.all_gather_object(sig)
+        assert all(s == sigs[0] for s in sigs)
+        assert desc["rows"][0] == n and len(desc["rows"]) >= 3
+        q.put((rank, "ok"))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:      # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("size", [2, 3])
+def test_packed_setup_exchange_and_distributed_hierarchy(size):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_setup_worker, args=(r, size, port, q)) for r in range(size)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(size)]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[1] == "ok", f"rank {r[0]}:\n{r[1]}"
