@@ -33,8 +33,12 @@ def _worker(rank, size, port, q, rtol=1e-13, extra=None, N=16, kind="square", pc
         import torch.distributed as dist
         torch.cuda.set_device(0)
         dist.init_process_group("gloo", rank=rank, world_size=size)
-        from parity_utils import ci_config, run_native
-        cfg = ci_config(N=N, steps=2, rtol=rtol, kind=kind, pc=pc)
+        from parity_utils import ci_config, run_native, tissue_config
+        if kind.startswith("tissue"):       # "tissue<dim>:<m>": membrane-dominated lattice cut by recursive coordinate bisection
+            tdim, tm = int(kind[6]), int(kind.split(":")[1])
+            cfg = tissue_config(tdim, N, tm, steps=2, rtol=rtol, pc=pc, stimulus=True, width=1)
+        else:
+            cfg = ci_config(N=N, steps=2, rtol=rtol, kind=kind, pc=pc)
         for k, v in (extra or {}).items():
             cfg["solver"]["ksp_settings"][k] = v
         s = run_native(cfg)
@@ -227,3 +231,33 @@ def test_native_exchange_moves_a_multi_megabyte_halo_over_four_ranks():
         assert r[4] == 0 and r[5], "forward halo wrong"
         assert r[6] == 0 and r[7], "all-reduce wrong"
         assert r[8] >= 2_000_000
+
+
+@pytest.mark.parametrize("size,kind,N,pc", [(2, "tissue3:3", 13, "btcc"), (4, "tissue2:6", 25, "hypre")])
+def test_partitioned_tissue_surrogate_matches_oracle(size, kind, N, pc):
+    """configs[3] shape over several ranks: the tissue lattice (one tag per cell, stimulus region) cut by the general
+    partitioner (recursive coordinate bisection -- cells ARE split between ranks), global AMG, native exchange; against the
+    oracle's sparse-LU run on the whole mesh."""
+    res = _run(size, rtol=1e-12, N=N, kind=kind, pc=pc, comm="p2p")
+    sys.path.insert(0, os.path.join(ROOT, "knp-emi-cgx_amd"))
+    import knpemi_oracle as K
+    from cgx_hip import mesh as meshmod
+    from parity_utils import tissue_config
+    tdim, tm = int(kind[6]), int(kind.split(":")[1])
+    cfg = tissue_config(tdim, N, tm, steps=2, rtol=1e-12, pc=pc, stimulus=True, width=1)
+    coords, cells, tags, _, _ = meshmod.load_mesh(cfg["cell_tag_file"], cfg["facet_tag_file"], 1e-6)
+    ctags = tuple(cfg["ics_tags"])
+    gamma, gtags, _ = meshmod.gamma_integration_entities(cells, tags, ctags, (1,), "intra")
+    lo, hi = cfg["stimulus_region"]["range"]
+    o = K.OracleKNPEMI(coords, cells, tags, intra_tags=ctags, extra_tag=1, gamma=gamma, gamma_tag=gtags,
+                       models=[K.Model("neuronal_ct", ctags), K.Model("hh", ctags), K.Model("atp", ctags)], mesh_conversion_factor=1.0,
+                       stimulus_tags=ctags, stimulus_region=(0, lo * 1e-6, hi * 1e-6))
+    o.run(2, solver="lu_gauge")
+    oi, oe = o.potential_norms()
+    phim = np.zeros(o.n_v)
+    for r in res:
+        assert abs(r[2] - oi) <= 1e-6 * oi
+        assert r[7] == o.n_dof
+        phim[r[4]] = r[5]
+    gam = (o.lay.node_i >= 0) & (o.lay.node_e >= 0)
+    assert np.allclose(phim[gam], o.phi_m[gam], rtol=1e-6)
