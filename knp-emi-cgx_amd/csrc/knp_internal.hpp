@@ -272,7 +272,7 @@ struct knp_ctx {
     int64_t n_allreduce = 0, n_halo = 0, n_readback = 0;
     // profiling
     int prof_on = 0;
-    unsigned prof_tick = 0;   // the SpMV class binds events to every 4th launch only
+    std::vector<hipEvent_t> prof_pool;   // recycled timing events
     struct ProfRec { hipEvent_t a, b; int cls; };
     std::vector<ProfRec> prof_recs;
     double prof_ms[KNP_NPROF] = {0, 0, 0, 0, 0};

@@ -1618,6 +1618,18 @@ static FieldPtrs make_fields(const knp_fields* f) {
     return o;
 }
 
+// timing events are recycled through a pool: creating them inside the timed region costs host time per launch
+static hipEvent_t prof_event(knp_ctx* ctx) {
+    if (!ctx->prof_pool.empty()) {
+        hipEvent_t e = ctx->prof_pool.back();
+        ctx->prof_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
 // profiling scope: records a pair of events around a group of launches when enabled
 struct ProfScope {
     knp_ctx* c;
@@ -1625,7 +1637,9 @@ struct ProfScope {
     int cls;
     ProfScope(knp_ctx* ctx, int cls_) : c(ctx), cls(cls_) {
         if ((c->prof_on >> cls) & 1) {
-            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+            a = prof_event(c);
+            b = prof_event(c);
+            if (!a || !b) { a = b = nullptr; return; }
             (void)hipEventRecord(a, c->stream);
         }
     }
@@ -1646,11 +1660,31 @@ static int prof_collect(knp_ctx* ctx) {
             ctx->prof_ms[r.cls] += ms;
             ctx->prof_n[r.cls] += 1;
         }
-        (void)hipEventDestroy(r.a);
-        (void)hipEventDestroy(r.b);
+        ctx->prof_pool.push_back(r.a);
+        ctx->prof_pool.push_back(r.b);
     }
     ctx->prof_recs.clear();
     return KNP_OK;
+}
+
+// recycle the events of launches that have completed, without synchronising (called once per solve)
+static void prof_collect_ready(knp_ctx* ctx) {
+    if (ctx->prof_recs.size() < 64) return;
+    size_t keep = 0;
+    for (size_t i = 0; i < ctx->prof_recs.size(); ++i) {
+        auto r = ctx->prof_recs[i];
+        float ms = 0.f;
+        if (hipEventQuery(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            ctx->prof_ms[r.cls] += ms;
+            ctx->prof_n[r.cls] += 1;
+            ctx->prof_pool.push_back(r.a);
+            ctx->prof_pool.push_back(r.b);
+        } else {
+            ctx->prof_recs[keep++] = r;
+        }
+    }
+    ctx->prof_recs.resize(keep);
+    (void)hipGetLastError();   // hipEventQuery reports hipErrorNotReady through the sticky error
 }
 
 extern "C" {
@@ -1798,6 +1832,7 @@ int knp_destroy(knp_ctx* ctx) {
     knp_p2p_free(ctx);
     knp_jit_release(ctx);
     for (auto& r : ctx->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto& e : ctx->prof_pool) (void)hipEventDestroy(e);
     dev_free(ctx->d_cells); dev_free(ctx->d_cell_side); dev_free(ctx->d_coords);
     dev_free(ctx->d_node_vertex); dev_free(ctx->d_node_side); dev_free(ctx->d_node_i); dev_free(ctx->d_node_e);
     dev_free(ctx->d_pair_ptr); dev_free(ctx->d_pair_col); dev_free(ctx->d_pair_row);
@@ -2346,8 +2381,10 @@ static int ensure_work(knp_ctx* ctx, int restart) {
 static int spmv_A(knp_ctx* ctx, double* x, const double* b, double* y, bool residual) {
     const KnpHostGraph& g = ctx->g;
     hipEvent_t ea = nullptr, eb = nullptr;
-    if ((ctx->prof_on & 1) && (ctx->prof_tick++ & 3) == 0) {   // class 0: events tied to the kernel's begin / end, every 4th launch
-        if (hipEventCreate(&ea) != hipSuccess || hipEventCreate(&eb) != hipSuccess) { ea = eb = nullptr; }
+    if (ctx->prof_on & 1) {   // class 0: events tied to the kernel's begin / end (recycled: no event creation in the timed loop)
+        ea = prof_event(ctx);
+        eb = prof_event(ctx);
+        if (!ea || !eb) ea = eb = nullptr;
     }
     static const bool no_split = getenv("KNP_SPMV_SPLIT") && atoi(getenv("KNP_SPMV_SPLIT")) == 0;
     if (ctx->p2p_fine >= 0 && ctx->n_bnd > 0 && ctx->n_int > 0 && !no_split) {
@@ -3097,6 +3134,7 @@ int knp_gmres_solve(knp_ctx* ctx, const double* b, double* x, double rtol, doubl
     if (!ctx->have_A) { ctx->err = "matrix not assembled"; return KNP_E_STATE; }
     if (restart < 1 || restart > RED_SLOTS - 8 || max_it < 0) { ctx->err = "restart must be in [1,56]"; return KNP_E_ARG; }
     KCHK(ensure_work(ctx, restart));
+    prof_collect_ready(ctx);
     const int n = ctx->n_dof_owned;
     const int64_t ldv = ctx->n_dof_local;
     const int nb = ctx->n_red_blocks;

@@ -45,4 +45,6 @@ def test_time_kernels_reports_one_and_all_cores():
     h = amg.build_hierarchy(P, coarse_size=100)
     out = T.time_kernels(o, lambda wrap: (lambda hh: K.pc_amg_vcycle(hh.levels, hh.coarse_inv, 1, 1, 1))(wrap(h)), budget_s=1.0, max_steps=2)
     assert out["kind"] == "port-omp" and out["threads_1"]["cores"] == 1 and out["threads_1"]["value"] > 0
-    assert out[f"threads_{out['host_cores']}" if out["host_cores"] > 1 else "threads_1"]["value"] > 0
+    assert out["parallel_threads_chosen_by_probe"] >= 1
+    if out["parallel_threads_chosen_by_probe"] > 1:
+        assert out["threads_all"]["cores"] == out["parallel_threads_chosen_by_probe"] and out["threads_all"]["value"] > 0
