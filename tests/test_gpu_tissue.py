@@ -172,8 +172,8 @@ def test_membrane_dominated_surrogate_at_scale():
 def test_hundred_steps_hh_surrogate_invariants():
     """BASELINE configs[4] shape (tissue + Hodgkin-Huxley gating, 100 implicit steps) on one GPU: 8^3 cells, one tag each,
     stimulus on the cells of one half.  Invariants the reference states or implies: every solve converges; the sum of the
-    potential unknowns keeps its initial value (null-space projection, KNPEMIx_solver.py:297-335); total ion amounts are
-    conserved (zero-flux boundary, print_conservation KNPEMIx_problem.py:807-843); gating variables stay in [0, 1]; the
+    potential unknowns keeps its initial value (null-space projection, KNPEMIx_solver.py:297-335); total charge is
+    conserved (zero-flux boundary; cf. print_conservation KNPEMIx_problem.py:807-843); gating variables stay in [0, 1]; the
     stimulated half depolarises, the other half does not."""
     from CGx.KNPEMI.KNPEMIx_solver import SolverKNPEMI
     cfg = tissue_config(3, 33, 8, steps=100, rtol=1e-9, pc="btcc", stimulus=True, width=1)
@@ -188,8 +188,13 @@ def test_hundred_steps_hh_surrogate_invariants():
     x = be.x.cpu().numpy()
     n_intra = int((be.node_i >= 0).sum())
     assert abs(x[3::4].sum() - (-0.07 * n_intra)) <= 1e-8 * 0.07 * n_intra
+    # Conservation: summing the rows of the scheme over all test functions, the stiffness terms vanish and the membrane terms of
+    # the two sides cancel for the CHARGE sum_k z_k k (sum_k alpha^k = 1 on both sides); the individual species are only
+    # conserved up to the difference of the capacitive split alpha_i^k - alpha_e^k (KNPEMIx_problem.py:582-583, 609-610)
     tot = _ion_totals(p)
-    assert np.all(np.abs(tot - tot0) <= 1e-7 * np.abs(tot0)), (tot, tot0)
+    z = np.array([1.0, 1.0, -1.0])
+    assert abs(z @ (tot - tot0)) <= 1e-7 * np.abs(tot0).sum(), (tot, tot0)
+    assert np.all(np.abs(tot - tot0) <= 2e-3 * np.abs(tot0)), (tot, tot0)
     for nm in ("n", "m", "h"):
         g = getattr(p, nm).numpy()
         assert g.min() >= 0.0 and g.max() <= 1.0
