@@ -291,7 +291,8 @@ int knp_profile_reset(knp_ctx* ctx);
  * (VecMDot/VecNorm reductions, VecScatter halos) behind KNPEMIx_solver.py:435 */
 enum { KNP_ST_BNORM = 0 /* ||B b|| of the last solve */, KNP_ST_ALLREDUCE = 1 /* reductions over ranks */,
        KNP_ST_HALO = 2 /* fine-level halo exchanges */, KNP_ST_READBACK = 3 /* host waits on a reduced value */,
-       KNP_ST_FUSED = 4 /* bit h set: hierarchy h runs the fused V(1,1) cycle */,
+       KNP_ST_FUSED = 4 /* bit h set: hierarchy h runs the fused V(1,1) cycle; bit 2+h: its level 0 runs fused inside the
+                           level-by-level cycle (distributed hierarchies) */,
        KNP_ST_NORM_FALLBACK = 5 /* GMRES iterations whose norm needed a second reduction (cancellation guard) */, KNP_ST_COUNT = 8 };
 int knp_get_stats(const knp_ctx* ctx, double* out /* host [KNP_ST_COUNT] */);
 

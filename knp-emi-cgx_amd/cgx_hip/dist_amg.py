@@ -161,7 +161,7 @@ class LevelHalo:
 
 
 class DistLevel:
-    __slots__ = ("A", "dinv", "lambda_max", "P", "P_loc", "R", "n_own", "n_loc", "halo", "gid_start", "ghost_gid",
+    __slots__ = ("A", "dinv", "lambda_max", "P", "P_loc", "R", "S", "n_own", "n_loc", "halo", "gid_start", "ghost_gid",
                  "ghost_owner", "replicated", "n_coarse_own", "n_coarse_loc", "repl_n", "repl_offset")
 
 
@@ -197,7 +197,7 @@ def build_distributed_hierarchy(comm, P_loc: sp.csr_matrix, halo0: LevelHalo, ow
         L = DistLevel()
         L.A, L.dinv, L.lambda_max, L.n_own, L.n_loc, L.halo = A, dinv, lam, n_own, n_loc, halo
         L.gid_start, L.ghost_gid, L.ghost_owner = gid_start, ghost_gid, ghost_owner
-        L.P = L.R = L.P_loc = None
+        L.P = L.R = L.P_loc = L.S = None
         L.replicated = False
         n_glob = int(comm.allreduce_sum(float((diag != 0.0).sum())))
         if len(levels) >= max_levels - 1:
@@ -262,6 +262,8 @@ def build_distributed_hierarchy(comm, P_loc: sp.csr_matrix, halo0: LevelHalo, ow
             L.replicated = True
             L.n_coarse_own, L.n_coarse_loc = int(nagg), nagg_glob
             L.repl_n, L.repl_offset = nagg_glob, int(offs[rank])
+            if len(levels) == 0:
+                L.S = _post_smoothed(X, A, dinv, lam, L.P, L.P_loc)
             levels.append(L)
             mine_blk = [Ac_glob.indptr.astype(np.int64), Ac_glob.indices.astype(np.int64), Ac_glob.data]
             got = exchange_arrays(comm, {r: mine_blk for r in range(size) if r != rank})
@@ -283,6 +285,8 @@ def build_distributed_hierarchy(comm, P_loc: sp.csr_matrix, halo0: LevelHalo, ow
         L.P_loc = relabel(Pm_loc, n_loc)                  # + rows of the ghost nodes
         L.R = L.P.T.tocsr()                               # n_c_loc x n_own (ghost rows -> reverse halo to their owners)
         L.n_coarse_own, L.n_coarse_loc = int(nagg), n_c_loc
+        if len(levels) == 0:
+            L.S = _post_smoothed(X, A, dinv, lam, L.P, L.P_loc)
         levels.append(L)
         A = relabel(Ac_glob, int(nagg))
         A.sort_indices()
@@ -290,6 +294,15 @@ def build_distributed_hierarchy(comm, P_loc: sp.csr_matrix, halo0: LevelHalo, ow
         ghost_gid = ghost_cols.astype(np.int64)
         ghost_owner = (np.searchsorted(offs, ghost_gid, side="right") - 1).astype(np.int64)
         halo = LevelHalo(comm, int(nagg), ghost_gid, ghost_owner, gid_start, device)
+
+
+def _post_smoothed(X, A, dinv, lam, P_own, P_loc):
+    """S = (I - c Dinv A) P for the owned rows (A: owned rows x local columns, P_loc: prolongator rows of the owned AND the ghost
+    nodes): prolongation + post-smoothing step of level 0 as one operator (amg.post_smoothed_prolongator, distributed)."""
+    AP = X.matmul(A.tocsr(), P_loc.tocsr())
+    S = (P_own - sp.diags(amg.cheby_first_coefficient(lam) * dinv) @ AP).tocsr()
+    S.sort_indices()
+    return S
 
 
 def _ghost_strength(A, n_own, theta, diag_own, halo):
@@ -384,6 +397,9 @@ def upload(lib, ctx, check, levels, tail, pre=1, post=1, cheby_degree=2, index=0
             check(lib.knp_amg_set_level(ctx, index, l, L.n_own, L.n_loc, ip(rp), ip(ci), fp(va), fp(dinv), float(L.lambda_max),
                                         0, None, None, None, None, None, None))
         check(lib.knp_amg_set_level_mode(ctx, index, l, 1, int(L.repl_n) if L.replicated else 0))
+        if getattr(L, "S", None) is not None:
+            Srp, Sci, Sv = arrs(L.S)
+            check(lib.knp_amg_set_level_smoothed(ctx, index, l, L.n_own, ip(Srp), ip(Sci), fp(Sv)))
         if L.P_loc is not None and L.n_loc > L.n_own:
             Prp, Pci, Pv = arrs(L.P_loc)
             check(lib.knp_amg_set_level_prolongator(ctx, index, l, L.n_loc, ip(Prp), ip(Pci), fp(Pv)))

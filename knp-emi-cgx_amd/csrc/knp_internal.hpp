@@ -138,6 +138,7 @@ struct KnpAmgHier {
     float* cinv_f = nullptr;
     // fused V(1,1) cycle (knp_pc_setup decides): Pt = P Dinv of level 0, fp64 or fp32, 4 fields per pair; potential part compact
     int fused = 0;
+    int l0_fused = 0;   // level 0 in fused form inside the level-by-level cycle (distributed hierarchies)
     double *pt = nullptr, *pt_phi = nullptr;
     float *pt_f = nullptr, *pt_phi_f = nullptr;
 };

@@ -737,7 +737,8 @@ static void launch_restrict_first_t(hipStream_t st, int lanes, int n_rows, const
 // and with S = (I - c2 Dinv A) Pprol (one sparse product at setup) the prolongation and the post-smoothing step are
 //   up   (any level):  x = x0 + c2 Dinv r + S xc
 // -- the same V-cycle, two gathers per level instead of four kernels, no intermediate iterate.
-// FM 0: all four fields, 1: ion fields (both on vectors with 4 unknowns per node), 2: potential on COMPACT vectors [n_nodes]
+// FM 0: all four fields, 1: ion fields (both on vectors with 4 unknowns per node), 2: potential on COMPACT vectors [n_nodes],
+// 3: potential on vectors with 4 unknowns per node (distributed levels keep the DoF layout their halo plans were built for)
 // ------------------------------------------------------------------------------------------
 template <int G, int FM, typename VT>
 __global__ void __launch_bounds__(NT)
@@ -749,14 +750,15 @@ k_l0_down(int n_nodes, const int32_t* __restrict__ pair_ptr, const int32_t* __re
     if (node < n_nodes) {
         const int p0 = pair_ptr[node];
         const int deg = pair_ptr[node + 1] - p0;
-        if (FM == 2) {   // 4 B value + 4 B index + 8 B gather per pair: four predicated trips in flight per lane (see row_dot4)
+        if (FM >= 2) {   // 4 B value + 4 B index + 8 B gather per pair: four predicated trips in flight per lane (see row_dot4)
             const int32_t* __restrict__ col = pair_col + p0;
             const VT* __restrict__ val = pt + p0;
+            constexpr int ST = FM == 3 ? 4 : 1, OF = FM == 3 ? 3 : 0;
             for (int q = lane; q < deg; q += 4 * G) {
                 const int qb = min(q + G, deg - 1), qc = min(q + 2 * G, deg - 1), qd = min(q + 3 * G, deg - 1);
                 const int na = col[q], nb = col[qb], nc = col[qc], nd = col[qd];
                 const double va = (double)val[q], vb = (double)val[qb], vc = (double)val[qc], vd = (double)val[qd];
-                const double xa = b[na], xb = b[nb], xc = b[nc], xd = b[nd];
+                const double xa = b[ST * (size_t)na + OF], xb = b[ST * (size_t)nb + OF], xc = b[ST * (size_t)nc + OF], xd = b[ST * (size_t)nd + OF];
                 s3 += va * xa;
                 if (q + G < deg) s3 += vb * xb;
                 if (q + 2 * G < deg) s3 += vc * xc;
@@ -800,7 +802,7 @@ k_l0_down(int n_nodes, const int32_t* __restrict__ pair_ptr, const int32_t* __re
     }
 #pragma unroll
     for (int o = G >> 1; o > 0; o >>= 1) {
-        if (FM != 2) {
+        if (FM < 2) {
             s0 += __shfl_xor(s0, o, G);
             s1 += __shfl_xor(s1, o, G);
             s2 += __shfl_xor(s2, o, G);
@@ -810,6 +812,8 @@ k_l0_down(int n_nodes, const int32_t* __restrict__ pair_ptr, const int32_t* __re
     if (lane == 0 && node < n_nodes) {
         if (FM == 2) {
             r[node] = b[node] - c * s3;
+        } else if (FM == 3) {
+            r[4 * (size_t)node + 3] = b[4 * (size_t)node + 3] - c * s3;
         } else {
             const size_t i = 4 * (size_t)node;
             const double2 b0 = *reinterpret_cast<const double2*>(b + i);
@@ -833,6 +837,7 @@ static void launch_l0_down_t(hipStream_t st, int G, int n_nodes, const int32_t* 
 template <typename VT>
 static void launch_l0_down(hipStream_t st, int fm, int G, int n_nodes, const int32_t* pp, const int32_t* pc, const VT* pt, const double* b, double c, double* r) {
     if (fm == 2) launch_l0_down_t<2, VT>(st, G, n_nodes, pp, pc, pt, b, c, r);
+    else if (fm == 3) launch_l0_down_t<3, VT>(st, G, n_nodes, pp, pc, pt, b, c, r);
     else if (fm == 1) launch_l0_down_t<1, VT>(st, G, n_nodes, pp, pc, pt, b, c, r);
     else launch_l0_down_t<0, VT>(st, G, n_nodes, pp, pc, pt, b, c, r);
 }
@@ -2626,14 +2631,24 @@ static int build_fused_data(knp_ctx* ctx, KnpAmgHier& H) {
     const int64_t np = ctx->n_pairs;
     const int nblk = (int)std::min<int64_t>(nblocks(np), 8192);
     const bool phi = H.native0 == 3;
+    // columns of ghost nodes are scaled with the ghost nodes' inverse diagonal: one halo of it (collective: every rank gets here)
+    const double* dinv_loc = L.inv_diag;
+    double* dinv_tmp = nullptr;
+    if (ctx->g.n_nodes > ctx->g.n_nodes_owned) {
+        HIPCHK(hipMalloc((void**)&dinv_tmp, (size_t)ctx->n_dof_local * sizeof(double)));
+        HIPCHK(hipMemsetAsync(dinv_tmp, 0, (size_t)ctx->n_dof_local * sizeof(double), ctx->stream));
+        HIPCHK(hipMemcpyAsync(dinv_tmp, L.inv_diag, (size_t)ctx->n_dof_owned * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        KCHK(halo_update(ctx, dinv_tmp));
+        dinv_loc = dinv_tmp;
+    }
     if (ctx->amg_fp32) {
         if (phi) HIPCHK(hipMalloc((void**)&H.pt_phi_f, std::max<int64_t>(np, 1) * sizeof(float)));
         else HIPCHK(hipMalloc((void**)&H.pt_f, std::max<int64_t>(4 * np, 1) * sizeof(float)));
-        hipLaunchKernelGGL((k_build_pt<float>), dim3(nblk), dim3(NT), 0, ctx->stream, np, ctx->d_pair_col, ctx->d_p_vals, L.inv_diag, H.pt_f, H.pt_phi_f);
+        hipLaunchKernelGGL((k_build_pt<float>), dim3(nblk), dim3(NT), 0, ctx->stream, np, ctx->d_pair_col, ctx->d_p_vals, dinv_loc, H.pt_f, H.pt_phi_f);
     } else {
         if (phi) HIPCHK(hipMalloc((void**)&H.pt_phi, std::max<int64_t>(np, 1) * sizeof(double)));
         else HIPCHK(hipMalloc((void**)&H.pt, std::max<int64_t>(4 * np, 1) * sizeof(double)));
-        hipLaunchKernelGGL((k_build_pt<double>), dim3(nblk), dim3(NT), 0, ctx->stream, np, ctx->d_pair_col, ctx->d_p_vals, L.inv_diag, H.pt, H.pt_phi);
+        hipLaunchKernelGGL((k_build_pt<double>), dim3(nblk), dim3(NT), 0, ctx->stream, np, ctx->d_pair_col, ctx->d_p_vals, dinv_loc, H.pt, H.pt_phi);
     }
     // The dense coarse inverse of the ION hierarchy (well conditioned: M + dt D K) is stored in fp32 like the other operators
     // of the mixed-precision preconditioner; the potential hierarchy's stays fp64 (nearly singular, cond ~1e8).
@@ -2657,6 +2672,10 @@ static int build_fused_data(knp_ctx* ctx, KnpAmgHier& H) {
         }
     }
     HIPCHK(hipGetLastError());
+    if (dinv_tmp) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(dinv_tmp);
+    }
     return KNP_OK;
 }
 
@@ -2787,11 +2806,29 @@ static double* amg_vcycle(knp_ctx* ctx, KnpAmgHier& H, int l, const double* b, d
     }
     KnpAmgLevel& C = H.lv[l + 1];
     const int nc = L.n_coarse;
+    const int hidx = (int)(&H - ctx->hier);
+    // Level 0 in fused form inside the level-by-level cycle (distributed hierarchies): pre-smoothing + residual as one gather
+    // with P Dinv (after the halo of the INPUT: x0 = c Dinv b is local, its ghost values follow from the ghost b), and below
+    // prolongation + post-smoothing as one gather with S; the levels in between keep their exchanges.
+    const bool f0 = (l == 0) && H.l0_fused;
     bool zero = true;
+    if (f0) {
+        const double c0 = 1.0 / (0.5 * (1.1 + 0.1) * L.lambda_max);
+        if (L.dist && level_comm_on(ctx)) level_exchange(ctx, hidx, 0, 0, const_cast<double*>(b));
+        const int nn = ctx->g.n_nodes_owned;
+        const int fm = H.native0 == 1 ? 0 : H.native0 == 2 ? 1 : 3;
+        if (fm == 3) {
+            const int Gp = std::max(2, ctx->pc_group / 2);
+            if (H.pt_phi_f) launch_l0_down<float>(st, 3, Gp, nn, ctx->d_pair_ptr, ctx->d_pair_col, H.pt_phi_f, b, c0, L.r);
+            else launch_l0_down<double>(st, 3, Gp, nn, ctx->d_pair_ptr, ctx->d_pair_col, H.pt_phi, b, c0, L.r);
+        } else {
+            if (H.pt_f) launch_l0_down<float>(st, fm, ctx->pc_group, nn, ctx->d_pair_ptr, ctx->d_pair_col, H.pt_f, b, c0, L.r);
+            else launch_l0_down<double>(st, fm, ctx->pc_group, nn, ctx->d_pair_ptr, ctx->d_pair_col, H.pt, b, c0, L.r);
+        }
+    } else {
     for (int sw = 0; sw < H.pre; ++sw) { amg_smooth(ctx, H, l, b, &cur, bufA, bufB, zero, zero && first_done); zero = false; }
     if (zero) hipLaunchKernelGGL(k_fill, dim3(std::min(nblocks(L.n), 2048)), dim3(NT), 0, st, L.n, 0.0, cur);
     // r = b - A x ; b_c = R r
-    const int hidx = (int)(&H - ctx->hier);
     if (L.dist && level_comm_on(ctx)) level_exchange(ctx, hidx, l, 0, cur);
     if (l == 0 && H.native0 > 0)
         launch_pnode<1>(st, H.native0 - 1, ctx->pc_group, ctx->g.n_nodes_owned,
@@ -2799,6 +2836,7 @@ static double* amg_vcycle(knp_ctx* ctx, KnpAmgHier& H, int l, const double* b, d
                         ctx->d_pair_col, ctx->d_p_vals, ctx->d_p_vals_f, L.inv_diag, b, cur, 0.0, 0.0, L.d, L.r);
     else
         launch_spmv_mp<1>(st, L.A_lanes, L.n, L.A_rp, L.A_ci, L.A_v, L.A_vf, cur, b, L.r);
+    }
     // the coarse level starts with a Chebyshev step from a zero guess unless it is the dense solve or has no smoothing
     // before its own restriction; that step is pointwise in b_c and is fused into the restriction when b_c is complete
     // after this kernel (no reverse halo / all-reduce to follow)
@@ -2820,6 +2858,15 @@ static double* amg_vcycle(knp_ctx* ctx, KnpAmgHier& H, int l, const double* b, d
     }
     double* xc = amg_vcycle(ctx, H, l + 1, C.b, nullptr, fuse_first);
     if (C.dist && level_comm_on(ctx) && L.repl_n == 0) level_exchange(ctx, hidx, l + 1, 0, xc);
+    if (f0) {   // x = c Dinv b + c Dinv r + S x_c, straight into the caller's vector
+        const double c0 = 1.0 / (0.5 * (1.1 + 0.1) * L.lambda_max);
+        const int n_act = L.S_n_act > 0 ? L.S_n_act : L.S_rows;
+        const int32_t* rp = L.S_n_act > 0 ? L.S_act_rp : L.S_rp;
+        const int32_t* rows = L.S_n_act > 0 ? L.S_act_rows : nullptr;
+        if (L.S_vf) launch_level_up_t<float, 0>(st, L.S_lanes, n_act, rows, rp, L.S_ci, L.S_vf, xc, L.inv_diag, b, L.r, nullptr, c0, c0, bufA, nullptr);
+        else launch_level_up_t<double, 0>(st, L.S_lanes, n_act, rows, rp, L.S_ci, L.S_v, xc, L.inv_diag, b, L.r, nullptr, c0, c0, bufA, nullptr);
+        return bufA;
+    }
     // x += P x_c (fused)
     // with prolongator rows for the ghost entries (distributed levels) the ghosts of `cur` stay current: they held the
     // pre-smoothed iterate since the halo before the residual, and get the same correction as on their owner
@@ -2943,6 +2990,14 @@ int knp_pc_setup(knp_ctx* ctx, int32_t kind) {
         const bool ok = fused_eligible(ctx, ctx->hier[0]) && fused_eligible(ctx, ctx->hier[1]) && ctx->hier[1].native0 == 3 && ctx->hier[0].native0 == 2 &&
                         ctx->hier[1].lv[0].S_n_act > 0 && ctx->hier[1].lv[0].S_act_rows_c && ctx->hier[1].lv[0].R_ci_c;
         ctx->hier[0].fused = ctx->hier[1].fused = ok ? 1 : 0;
+    }
+    for (int h = 0; h < KNP_MAX_HIER; ++h) {   // level 0 in fused form inside the level-by-level cycle (distributed hierarchies)
+        KnpAmgHier& H = ctx->hier[h];
+        const bool off = getenv("KNP_FUSED") && atoi(getenv("KNP_FUSED")) == 0;
+        const KnpAmgLevel& L0 = H.lv[0];
+        const bool have_pt = H.native0 == 3 ? (H.pt_phi || H.pt_phi_f) : (H.pt || H.pt_f);
+        H.l0_fused = (!off && !H.fused && H.native0 > 0 && H.levels >= 2 && H.cheby == 1 && H.pre == 1 && H.post == 1 && L0.S_rp &&
+                      L0.S_rows == L0.n && have_pt) ? 1 : 0;
     }
     if (kind == KNP_PC_VBJACOBI && ctx->have_A) {
         const KnpHostGraph& g = ctx->g;
@@ -3369,7 +3424,7 @@ int knp_get_stats(const knp_ctx* ctx, double* out) {
     out[KNP_ST_ALLREDUCE] = (double)ctx->n_allreduce;
     out[KNP_ST_HALO] = (double)ctx->n_halo;
     out[KNP_ST_READBACK] = (double)ctx->n_readback;
-    out[KNP_ST_FUSED] = (double)(ctx->hier[0].fused + 2 * ctx->hier[1].fused);
+    out[KNP_ST_FUSED] = (double)(ctx->hier[0].fused + 2 * ctx->hier[1].fused + 4 * ctx->hier[0].l0_fused + 8 * ctx->hier[1].l0_fused);
     out[KNP_ST_NORM_FALLBACK] = (double)ctx->n_norm_fallback;
     return KNP_OK;
 }
