@@ -271,7 +271,16 @@ def build_distributed_hierarchy(comm, P_loc: sp.csr_matrix, halo0: LevelHalo, ow
             parts = [got[r] if r in got else [np.zeros(1, np.int64), np.zeros(0, np.int64), np.zeros(0)] for r in range(size)]
             mats = [sp.csr_matrix((d, i, p), shape=(len(p) - 1, nagg_glob)) for (p, i, d) in parts]
             A_rep = sp.vstack(mats).tocsr()
-            tail = amg.build_hierarchy(A_rep, theta=theta * 0.25 ** len(levels), coarse_size=coarse_size)
+            # the replicated tail is an ordinary serial hierarchy: built on the device like the single-GPU one (same algorithm and
+            # priorities as the host version, which remains the fallback)
+            tail = None
+            if X.gpu:
+                try:
+                    tail = X.G.build_hierarchy(A_rep, theta=theta * 0.25 ** len(levels), coarse_size=coarse_size, device=X.dev)
+                except (RuntimeError, NotImplementedError):
+                    tail = None
+            if tail is None:
+                tail = amg.build_hierarchy(A_rep, theta=theta * 0.25 ** len(levels), coarse_size=coarse_size)
             return levels, tail
         col_map = np.full(nagg_glob, -1, dtype=np.int64)
         col_map[offs[rank]:offs[rank + 1]] = np.arange(nagg)
