@@ -267,7 +267,7 @@ def timed_run(case, args, world, dist, torch, steps, warmup, snapshot_at=None, a
 
 
 def main_case(args, world, rank, dist, torch):
-    """The headline measurement (+ CPU baseline and parity on rank 0 of a single-GPU run); returns (json dict, failure text or None)."""
+    """The headline measurement; returns (json dict, failure text or None, what the CPU baseline / parity legs need or None)."""
     # the parity snapshot is taken during warmup (never inside the timed region), at the last step the oracle sample covers
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     snap_at = min(args.warmup, args.cpu_steps + 1) if want_cpu and args.warmup >= 1 else None
@@ -307,13 +307,18 @@ def main_case(args, world, rank, dist, torch):
     if not out["config"]["converged_all"]:
         fail = "GMRES did not converge in every timed step"
 
-    # ---- CPU baseline (oracle, 1 core; C++/OpenMP twin at 1 core and all cores) + parity of the GPU run against it ----
+    # what the CPU legs need of this run (they run after the out-of-cache block, while the GPU would otherwise idle and clock down
+    # in front of it): solver parameters, the evaluation order of the cycle, the snapshot
+    info = None
     if want_cpu and not case["tissue"]:
-        cpu, par = cpu_baseline(case, args, solver, run["snap"])
-        out["cpu_baseline"], out["parity"] = cpu, par
-        if par is not None and not par["ok"]:
-            fail = f"GPU solution differs from the oracle beyond {PARITY_TOL:g}: {par}"
-    return out, fail
+        class _P:      # plain record: the device objects of this case can be freed
+            pass
+        sp_ = _P()
+        for k in ("amg_pre", "amg_post", "amg_cheby_degree", "amg_theta", "amg_coarse_size", "amg_fp32"):
+            setattr(sp_, k, getattr(solver, k))
+        sp_.fused = bool(be.stats()["fused"])
+        info = {"case": {"kind": case["kind"], "N": case["N"], "pc": case["pc"]}, "solver": sp_, "snap": run["snap"]}
+    return out, fail, info
 
 
 def main():
@@ -341,7 +346,7 @@ def main():
     else:
         torch.cuda.set_device(0)
 
-    out, fail = main_case(args, world, rank, dist, torch)
+    out, fail, info = main_case(args, world, rank, dist, torch)
 
     # ---- out-of-cache roofline: the 10^7-DoF-per-GPU point, same process, every kernel class timed with HIP events ----
     large = (args.large or "").lower()
@@ -350,6 +355,13 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
         out["roofline_large"] = large_block(args, torch, dist)
+
+    # ---- CPU baseline (oracle, 1 core; C/OpenMP twin at 1 core and all usable cores) + parity of the GPU run against it ----
+    if info is not None:
+        cpu, par = cpu_baseline(info["case"], args, info["solver"], info["snap"])
+        out["cpu_baseline"], out["parity"] = cpu, par
+        if par is not None and not par["ok"]:
+            fail = f"GPU solution differs from the oracle beyond {PARITY_TOL:g}: {par}"
 
     if rank == 0:
         print(json.dumps(out), flush=True)
@@ -402,7 +414,7 @@ def cpu_baseline(case, args, solver, snap):
     o = mk(N, models=mdl)
     pre, post, deg = solver.amg_pre, solver.amg_post, solver.amg_cheby_degree
 
-    fused = bool(solver.backend.stats()["fused"])                    # the order in which the library's cycle evaluates its operators
+    fused = solver.fused                                             # the order in which the library's cycle evaluates its operators
     rnd = amg.fp32_stored if solver.amg_fp32 else (lambda h, **k: h)    # ... and their values as it stores them
 
     built = {}

@@ -183,6 +183,31 @@ class Twin:
         return x, it
 
 
+def usable_cores():
+    """cores this process may actually use: affinity mask and cgroup CPU quota (v2 cpu.max, v1 cfs quota), whichever is smaller"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: (t.split()[0], t.split()[1])),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", None)):
+        try:
+            txt = open(path).read().strip()
+            if parse:
+                q, per = parse(txt)
+                if q != "max":
+                    n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+            else:
+                q = int(txt)
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+        except (OSError, ValueError, IndexError):
+            pass
+    return n
+
+
 def time_kernels(o, pc_factory, rtol=1e-9, budget_s=8.0, max_steps=3):
     """Continue the oracle's run with the C/OpenMP kernels, at 1 thread and at all cores.  ``pc_factory(wrap)`` returns the
     preconditioner built on ``wrap(hierarchy)`` operators.  Returns the dict that goes into cpu_baseline["omp_twin"]."""
@@ -195,14 +220,16 @@ def time_kernels(o, pc_factory, rtol=1e-9, budget_s=8.0, max_steps=3):
     out = {"kind": "port-omp", "unit": "MDoF/s", "host_cores": ncores,
            "what": "same timestep as the NumPy oracle with assembly, CSR SpMV (GMRES and every V-cycle level) and the dense coarse solve in "
                    "C/OpenMP (oracle/knpemi_cpu.c); not DOLFINx/PETSc"}
-    # "all cores": the box may expose more hardware threads than this job may use (cgroup share, affinity); the thread count of
-    # the parallel leg is the fastest of {2, 4, 8, ... host threads} on a short SpMV probe, and is reported
+    # "all cores": the box may expose more hardware threads than this job may use (cgroup share, affinity): candidates are the
+    # powers of two up to the usable count, the parallel leg runs with the one a short SpMV probe finds fastest, and says so
     A0 = tw.assemble_A()
     xv = np.ones(A0.shape[1])
     best, best_t = 1, None
-    cands = [1] + [c for c in (2, 4, 8, 16, 32, 64, 128, 256, 512) if c <= ncores]
-    if ncores not in cands:
-        cands.append(ncores)
+    usable = usable_cores()
+    out["usable_cores"] = usable
+    cands = [1] + [c for c in (2, 4, 8, 16, 32, 64, 128, 256, 512) if c <= usable]
+    if usable not in cands:
+        cands.append(usable)
     for c in cands:
         L.knp_cpu_set_threads(c)
         A0 @ xv
