@@ -26,6 +26,12 @@ struct KnpHostGraph {
     std::vector<int32_t> contrib_ptr;             // [n_pairs+1]
     std::vector<int32_t> contrib_cell;            // [n_contrib]
     std::vector<double> contrib_k;                // [n_contrib]
+    // same-side cells of every owned node and, per contribution, the position of its cell in the list of the pair's row node:
+    // the assembly stages the node's cell means in LDS once instead of gathering them per contribution
+    std::vector<int32_t> node_cell_ptr;           // [n_nodes_owned+1]
+    std::vector<int32_t> node_cell;               // [sum]
+    std::vector<uint8_t> contrib_slot;            // [n_contrib]
+    int max_node_cells = 0;
     // membrane graph
     std::vector<int32_t> fv;                      // [n_g*dim] facet vertices
     std::vector<double> fmeas;                    // [n_g]
@@ -166,6 +172,9 @@ struct knp_ctx {
     double *d_pair_M = nullptr, *d_pair_K = nullptr;
     int32_t *d_contrib_ptr = nullptr, *d_contrib_cell = nullptr;
     double* d_contrib_k = nullptr;
+    int32_t *d_node_cell_ptr = nullptr, *d_node_cell = nullptr;
+    uint8_t* d_contrib_slot = nullptr;
+    int asm_stage = 0;    // cells per node the staged assembly reserves LDS for (0: gather per contribution)
     int32_t* d_fv = nullptr;
     double* d_fmeas = nullptr;
     int32_t* d_gamma_prog = nullptr;

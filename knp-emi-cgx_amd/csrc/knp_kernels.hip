@@ -574,7 +574,7 @@ template <int G, bool COMPACT>   // COMPACT: t is the potential right-hand side 
 __global__ void __launch_bounds__(NT)
 k_phi_rhs(int n_nodes, double z0, double z1, double z2, const int32_t* __restrict__ pair_ptr,
           const int32_t* __restrict__ pair_col, const double* __restrict__ pair_M, const double* __restrict__ r,
-          const double* __restrict__ z, double* __restrict__ t) {
+          const double* __restrict__ z, const double* __restrict__ sc, double* __restrict__ t) {
     // t_phi = r_phi - sum_j z_j r_kj + M (sum_j z_j z_kj): equals r_phi - A_{phi,k} z_k for exact ion solves since
     // A_{phi,kj} = z_j (A_{kj,kj} - M) (KNPEMIx_problem.py:586-591,598,603,633-634), without the cancellation
     // that would amplify the V-cycle's error by 1/(1 - rho) ~ 10^2.
@@ -584,6 +584,18 @@ k_phi_rhs(int n_nodes, double z0, double z1, double z2, const int32_t* __restric
     if (node < n_nodes) {
         const int p0 = pair_ptr[node];
         const int deg = pair_ptr[node + 1] - p0;
+        if (COMPACT) {   // sc[nb] = sum_j z_j z_kj[nb] was formed once per node (k_ion_charge): one 8-byte gather per pair
+            for (int q = lane; q < deg; q += 4 * G) {
+                const int qb = min(q + G, deg - 1), qc = min(q + 2 * G, deg - 1), qd = min(q + 3 * G, deg - 1);
+                const int na = pair_col[p0 + q], nb = pair_col[p0 + qb], nc = pair_col[p0 + qc], nd = pair_col[p0 + qd];
+                const double ma = pair_M[p0 + q], mb = pair_M[p0 + qb], mc = pair_M[p0 + qc], md = pair_M[p0 + qd];
+                const double sa = sc[na], sb = sc[nb], scc = sc[nc], sd = sc[nd];
+                s += ma * sa;
+                if (q + G < deg) s += mb * sb;
+                if (q + 2 * G < deg) s += mc * scc;
+                if (q + 3 * G < deg) s += md * sd;
+            }
+        } else
         for (int q = lane; q < deg; q += 2 * G) {   // two predicated trips in flight per lane
             const int q2 = min(q + G, deg - 1);
             const int nb = pair_col[p0 + q], nb2 = pair_col[p0 + q2];
@@ -611,12 +623,26 @@ k_phi_rhs(int n_nodes, double z0, double z1, double z2, const int32_t* __restric
         }
     }
 }
+// sc[n] = sum_j z_j z_kj[n]: the ion charge of the ion correction at every owned node (node-indexed)
+__global__ void __launch_bounds__(NT) k_ion_charge(int n_nodes, double z0, double z1, double z2, const double* __restrict__ z, double* __restrict__ sc) {
+    for (int n = blockIdx.x * NT + threadIdx.x; n < n_nodes; n += gridDim.x * NT) {
+        const double2 a = *reinterpret_cast<const double2*>(z + 4 * (size_t)n);
+        sc[n] = z0 * a.x + z1 * a.y + z2 * z[4 * (size_t)n + 2];
+    }
+}
 template <bool COMPACT>
 static void launch_phi_rhs(knp_ctx* ctx, const double* r, const double* z, double* t) {
-    const int G = ctx->pc_group, n = ctx->g.n_nodes_owned;
+    const int n = ctx->g.n_nodes_owned;
+    const int G = COMPACT ? std::max(2, ctx->pc_group / 2) : ctx->pc_group;
     if (n <= 0) return;
-#define KNP_PR(GG) hipLaunchKernelGGL((k_phi_rhs<GG, COMPACT>), dim3(nblocks((int64_t)n * GG)), dim3(NT), 0, ctx->stream, n, ctx->z[0], ctx->z[1], ctx->z[2], ctx->d_pair_ptr, ctx->d_pair_col, ctx->d_pair_M, r, z, t)
+    const double* sc = nullptr;
+    if (COMPACT) {
+        hipLaunchKernelGGL(k_ion_charge, dim3(std::min(nblocks(n), 4096)), dim3(NT), 0, ctx->stream, n, ctx->z[0], ctx->z[1], ctx->z[2], z, ctx->d_w2);
+        sc = ctx->d_w2;
+    }
+#define KNP_PR(GG) hipLaunchKernelGGL((k_phi_rhs<GG, COMPACT>), dim3(nblocks((int64_t)n * GG)), dim3(NT), 0, ctx->stream, n, ctx->z[0], ctx->z[1], ctx->z[2], ctx->d_pair_ptr, ctx->d_pair_col, ctx->d_pair_M, r, z, sc, t)
     switch (G) {
+        case 2: KNP_PR(2); break;
         case 4: KNP_PR(4); break;
         case 8: KNP_PR(8); break;
         case 16: KNP_PR(16); break;
@@ -1397,25 +1423,31 @@ __global__ void __launch_bounds__(NT) k_cheby_first(int n, double c, const doubl
         x[e] = t;
     }
 }
-// y = M x, dense row-major n x n, one wave per row
-template <typename VT>
+// y = M x, dense row-major n x n.  WPR waves per row (a 2500-row coarse inverse with one wave per row is 2.4 waves per SIMD:
+// the row streams at one wave's latency; four waves per row keep ~10 waves per SIMD in flight), 16-byte loads, two trips in
+// flight per lane; rows are combined through LDS.
+template <typename VT, int WPR>
 __global__ void __launch_bounds__(NT) k_dense_matvec(int n, const VT* __restrict__ M, const double* __restrict__ x,
                                                      double* __restrict__ y) {
-    const int row = (blockIdx.x * NT + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
+    constexpr int RPB = (NT / 64) / WPR;          // rows per block
+    __shared__ double sm[NT / 64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * RPB + wave / WPR;
+    const int part = wave % WPR;
+    const int t = part * 64 + lane;               // position within the row's WPR*64 lanes
+    constexpr int TPR = WPR * 64;
     double s = 0.0;
     if (row < n) {
         const VT* __restrict__ m = M + (size_t)row * n;
         if (sizeof(VT) == 8 && (n & 1) == 0) {
-            // 16-B loads (the row start is 16-B aligned for even n), two independent accumulators
             const double2* m2 = reinterpret_cast<const double2*>(m);
             const double2* x2 = reinterpret_cast<const double2*>(x);
             const int n2 = n >> 1;
             double s0 = 0.0, s1 = 0.0;
-            int k = lane;
-            for (; k + 64 < n2; k += 128) {
-                const double2 a = m2[k], b = m2[k + 64];
-                const double2 xa = x2[k], xb = x2[k + 64];
+            int k = t;
+            for (; k + TPR < n2; k += 2 * TPR) {
+                const double2 a = m2[k], b = m2[k + TPR];
+                const double2 xa = x2[k], xb = x2[k + TPR];
                 s0 += a.x * xa.x + a.y * xa.y;
                 s1 += b.x * xb.x + b.y * xb.y;
             }
@@ -1426,15 +1458,14 @@ __global__ void __launch_bounds__(NT) k_dense_matvec(int n, const VT* __restrict
             }
             s = s0 + s1;
         } else if (sizeof(VT) == 4 && (n & 3) == 0) {
-            // fp32 storage: 16-B loads of four matrix entries, two 16-B loads of x, two trips in flight
             const float4* m4 = reinterpret_cast<const float4*>(m);
             const double2* x2 = reinterpret_cast<const double2*>(x);
             const int n4 = n >> 2;
             double s0 = 0.0, s1 = 0.0;
-            int k = lane;
-            for (; k + 64 < n4; k += 128) {
-                const float4 a = m4[k], b = m4[k + 64];
-                const double2 xa = x2[2 * k], xb = x2[2 * k + 1], xc = x2[2 * (k + 64)], xd = x2[2 * (k + 64) + 1];
+            int k = t;
+            for (; k + TPR < n4; k += 2 * TPR) {
+                const float4 a = m4[k], b = m4[k + TPR];
+                const double2 xa = x2[2 * k], xb = x2[2 * k + 1], xc = x2[2 * (k + TPR)], xd = x2[2 * (k + TPR) + 1];
                 s0 += (double)a.x * xa.x + (double)a.y * xa.y + (double)a.z * xb.x + (double)a.w * xb.y;
                 s1 += (double)b.x * xc.x + (double)b.y * xc.y + (double)b.z * xd.x + (double)b.w * xd.y;
             }
@@ -1445,11 +1476,28 @@ __global__ void __launch_bounds__(NT) k_dense_matvec(int n, const VT* __restrict
             }
             s = s0 + s1;
         } else {
-            for (int k = lane; k < n; k += 64) s += (double)m[k] * x[k];
+            for (int k = t; k < n; k += TPR) s += (double)m[k] * x[k];
         }
     }
     s = wave_sum(s);
-    if (lane == 0 && row < n) y[row] = s;
+    if (WPR == 1) {
+        if (lane == 0 && row < n) y[row] = s;
+    } else {
+        if (lane == 0) sm[wave] = s;
+        __syncthreads();
+        if (lane == 0 && part == 0 && row < n) {
+            double r = 0.0;
+#pragma unroll
+            for (int q = 0; q < WPR; ++q) r += sm[wave + q];
+            y[row] = r;
+        }
+    }
+}
+template <typename VT>
+static void launch_dense_matvec(hipStream_t st, int n, const VT* M, const double* x, double* y) {
+    if (n <= 0) return;
+    if (n >= 512) hipLaunchKernelGGL((k_dense_matvec<VT, 4>), dim3(n), dim3(NT), 0, st, n, M, x, y);                       // one row per block
+    else hipLaunchKernelGGL((k_dense_matvec<VT, 1>), dim3(nblocks((int64_t)n * 64)), dim3(NT), 0, st, n, M, x, y);       // one wave per row
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2791,9 +2839,9 @@ static double* amg_vcycle(knp_ctx* ctx, KnpAmgHier& H, int l, const double* b, d
     double* bufB = L.r2;
     if (last && H.nc > 0) {
         if (H.cinv_f)
-            hipLaunchKernelGGL((k_dense_matvec<float>), dim3(nblocks((int64_t)H.nc * 64)), dim3(NT), 0, st, H.nc, H.cinv_f, b, bufA);
+            launch_dense_matvec<float>(st, H.nc, H.cinv_f, b, bufA);
         else
-            hipLaunchKernelGGL((k_dense_matvec<double>), dim3(nblocks((int64_t)H.nc * 64)), dim3(NT), 0, st, H.nc, H.cinv, b, bufA);
+            launch_dense_matvec<double>(st, H.nc, H.cinv, b, bufA);
         return bufA;
     }
     const int flips = amg_flips(H, last);
@@ -2926,8 +2974,8 @@ static void amg_cycle_fused(knp_ctx* ctx, KnpAmgHier& H, const double* b, double
         if (l + 1 == nl - 1) {   // coarsest: b_c = R r ; x_c = Cinv b_c
             if (L.R_vf) launch_spmv_t<0, 0, float>(st, L.R_lanes, nc, L.R_rp, Rci, L.R_vf, L.r, nullptr, C.b);
             else launch_spmv_t<0, 0, double>(st, L.R_lanes, nc, L.R_rp, Rci, L.R_v, L.r, nullptr, C.b);
-            if (H.cinv_f) hipLaunchKernelGGL((k_dense_matvec<float>), dim3(nblocks((int64_t)H.nc * 64)), dim3(NT), 0, st, H.nc, H.cinv_f, C.b, C.x);
-            else hipLaunchKernelGGL((k_dense_matvec<double>), dim3(nblocks((int64_t)H.nc * 64)), dim3(NT), 0, st, H.nc, H.cinv, C.b, C.x);
+            if (H.cinv_f) launch_dense_matvec<float>(st, H.nc, H.cinv_f, C.b, C.x);
+            else launch_dense_matvec<double>(st, H.nc, H.cinv, C.b, C.x);
         } else {                 // b_c = R r ; x_c = c Dinv b_c (first Chebyshev step, fused) ; r_c = b_c - A_c x_c
             const double cc = cheb_c(C);
             if (L.R_vf) launch_restrict_first_t<float>(st, L.R_lanes, nc, L.R_rp, Rci, L.R_vf, L.r, C.b, cc, C.inv_diag, C.d, C.x);

@@ -16,6 +16,7 @@ namespace {
 struct Tup {
     int32_t nb, cell;
     int8_t la, lb;
+    int32_t slot;   // position of the cell in the row node's cell list
 };
 
 inline int node_of(const KnpHostGraph& g, int v, int side) { return side == 0 ? g.node_i[v] : g.node_e[v]; }
@@ -153,7 +154,12 @@ int knp_build_graph(const knp_mesh_desc* m, KnpHostGraph& g) {
     const int64_t np = tot_pairs;
     g.pair_col.resize(np); g.pair_row.resize(np); g.pair_M.assign(np, 0.0); g.pair_K.assign(np, 0.0);
     g.contrib_ptr.assign(np + 1, 0);
-    g.contrib_cell.resize(tot_con); g.contrib_k.resize(tot_con);
+    g.contrib_cell.resize(tot_con); g.contrib_k.resize(tot_con); g.contrib_slot.resize(tot_con);
+    g.node_cell_ptr.assign(nc_ptr.begin(), nc_ptr.end());
+    g.node_cell.resize(nc.size());
+    g.max_node_cells = 0;
+    for (int n = 0; n < no; ++n) g.max_node_cells = std::max(g.max_node_cells, nc_ptr[n + 1] - nc_ptr[n]);
+    for (size_t k = 0; k < nc.size(); ++k) g.node_cell[k] = nc[k] >> 2;
     const double mfac = 1.0 / ((dim + 1.0) * (dim + 2.0));
     bool degenerate = false;
 #pragma omp parallel
@@ -165,7 +171,7 @@ int knp_build_graph(const knp_mesh_desc* m, KnpHostGraph& g) {
             for (int k = nc_ptr[n]; k < nc_ptr[n + 1]; ++k) {
                 int c = nc[k] >> 2, la = nc[k] & 3;
                 for (int b = 0; b < nv1; ++b)
-                    tups.push_back({node_of(g, cells[(size_t)c * nv1 + b], side[c]), c, (int8_t)la, (int8_t)b});
+                    tups.push_back({node_of(g, cells[(size_t)c * nv1 + b], side[c]), c, (int8_t)la, (int8_t)b, (int32_t)(k - nc_ptr[n])});
             }
             std::stable_sort(tups.begin(), tups.end(), [](const Tup& x, const Tup& y) { return x.nb < y.nb; });
             int64_t p = g.pair_ptr[n] - 1;
@@ -189,6 +195,7 @@ int knp_build_graph(const knp_mesh_desc* m, KnpHostGraph& g) {
                 if (t.nb != n) {
                     g.contrib_cell[cc] = t.cell;
                     g.contrib_k[cc] = kab;
+                    g.contrib_slot[cc] = (uint8_t)std::min(t.slot, 255);
                     ++cc;
                 }
                 g.pair_K[p] += kab;
