@@ -205,11 +205,110 @@ k_assemble_nodes(int n_nodes, DevParams P, const int32_t* __restrict__ pair_ptr,
     }
     if (live && self_p >= 0) emit(self_p, -T0, -T1, -T2);
 }
+// The same with the cell means of the node's cells staged in LDS: a node's ~24 (3D) same-side cells are each gathered ONCE by
+// the group (24-byte records from the cell-mean array) instead of once per contribution (~72 per node: every cell feeds the
+// three off-diagonal pairs of the node it belongs to); a contribution is then 9 streamed bytes (K_ab(T), 1-byte slot) and three
+// LDS reads.  `cmax` = LDS slots reserved per group (>= the largest cell count of any owned node).
+template <bool PRECOND, bool TD_ONLY, int G>
+__global__ void __launch_bounds__(NT)
+k_assemble_nodes_staged(int n_nodes, DevParams P, int cmax, const int32_t* __restrict__ pair_ptr, const int32_t* __restrict__ pair_col,
+                        const uint8_t* __restrict__ node_side, const double* __restrict__ pair_M, const double* __restrict__ pair_K,
+                        const int32_t* __restrict__ contrib_ptr, const uint8_t* __restrict__ contrib_slot,
+                        const double* __restrict__ contrib_k, const int32_t* __restrict__ node_cell_ptr,
+                        const int32_t* __restrict__ node_cell, const double* __restrict__ cbar,
+                        double* __restrict__ at, double* __restrict__ ac) {
+    extern __shared__ double lds[];   // [NT / G][cmax][3]
+    const int node_raw = (blockIdx.x * NT + threadIdx.x) / G;
+    const int lane = threadIdx.x & (G - 1);
+    const bool live = node_raw < n_nodes;
+    const int node = live ? node_raw : n_nodes - 1;
+    double* mine = lds + (size_t)(threadIdx.x / G) * cmax * 3;
+    {
+        const int c0 = node_cell_ptr[node], c1 = node_cell_ptr[node + 1];
+        for (int i = c0 + lane; i < c1; i += G) {
+            const int cell = node_cell[i];
+            const double2 c01 = *reinterpret_cast<const double2*>(cbar + (size_t)4 * cell);
+            const double c2 = cbar[(size_t)4 * cell + 2];
+            double* d = mine + 3 * (i - c0);
+            d[0] = c01.x; d[1] = c01.y; d[2] = c2;
+        }
+    }
+    __syncthreads();
+    const int p0 = pair_ptr[node];
+    const int deg = pair_ptr[node + 1] - p0;
+    const int side = node_side[node];
+    const double D0 = side ? P.De[0] : P.Di[0], D1 = side ? P.De[1] : P.Di[1], D2 = side ? P.De[2] : P.Di[2];
+    const double f0 = P.dt * D0 * P.z[0] / P.psi, f1 = P.dt * D1 * P.z[1] / P.psi, f2 = P.dt * D2 * P.z[2] / P.psi;
+    auto emit = [&](int p, double S0, double S1, double S2) {
+        const double phiphi = f0 * P.z[0] * S0 + f1 * P.z[1] * S1 + f2 * P.z[2] * S2;
+        if (!PRECOND) {
+            *reinterpret_cast<double2*>(at + 4 * (size_t)p) = make_double2(f0 * S0, f1 * S1);
+            *reinterpret_cast<double2*>(at + 4 * (size_t)p + 2) = make_double2(f2 * S2, phiphi);
+            if (!TD_ONLY) {
+                const double M = pair_M[p], K = pair_K[p];
+                *reinterpret_cast<double2*>(ac + 6 * (size_t)p) = make_double2(M + P.dt * D0 * K, M + P.dt * D1 * K);
+                *reinterpret_cast<double2*>(ac + 6 * (size_t)p + 2) = make_double2(M + P.dt * D2 * K, P.dt * P.z[0] * D0 * K);
+                *reinterpret_cast<double2*>(ac + 6 * (size_t)p + 4) = make_double2(P.dt * P.z[1] * D1 * K, P.dt * P.z[2] * D2 * K);
+            }
+        } else {
+            const double M = pair_M[p], K = pair_K[p];
+            *reinterpret_cast<double2*>(at + 4 * (size_t)p) = make_double2(M + P.dt * D0 * K, M + P.dt * D1 * K);
+            *reinterpret_cast<double2*>(at + 4 * (size_t)p + 2) = make_double2(M + P.dt * D2 * K, phiphi);
+        }
+    };
+    double T0 = 0.0, T1 = 0.0, T2 = 0.0;
+    int self_p = -1;
+    for (int q = lane; q < deg; q += G) {
+        const int p = p0 + q;
+        if (pair_col[p] == node) { self_p = p; continue; }
+        double S0 = 0.0, S1 = 0.0, S2 = 0.0;
+        const int c1 = contrib_ptr[p + 1];
+        for (int c = contrib_ptr[p]; c < c1; c += 2) {
+            const int cb = min(c + 1, c1 - 1);
+            const double k = contrib_k[c], k2 = contrib_k[cb];
+            const double* u = mine + 3 * (int)contrib_slot[c];
+            const double* w = mine + 3 * (int)contrib_slot[cb];
+            S0 += k * u[0];
+            S1 += k * u[1];
+            S2 += k * u[2];
+            if (c + 1 < c1) {
+                S0 += k2 * w[0];
+                S1 += k2 * w[1];
+                S2 += k2 * w[2];
+            }
+        }
+        if (live) emit(p, S0, S1, S2);
+        T0 += S0; T1 += S1; T2 += S2;
+    }
+#pragma unroll
+    for (int o = G >> 1; o > 0; o >>= 1) {
+        T0 += __shfl_xor(T0, o, G);
+        T1 += __shfl_xor(T1, o, G);
+        T2 += __shfl_xor(T2, o, G);
+    }
+    if (live && self_p >= 0) emit(self_p, -T0, -T1, -T2);
+}
+
 template <bool PRECOND, bool TD_ONLY>
 static void launch_assemble_nodes(knp_ctx* ctx, const DevParams& P, double* at, double* ac) {
     const KnpHostGraph& g = ctx->g;
     const int n = g.n_nodes_owned;
     if (n <= 0) return;
+    if (ctx->asm_stage > 0) {   // cell means staged in LDS (default)
+        const int cmax = ctx->asm_stage;
+#define KNP_ASMS(GG) hipLaunchKernelGGL((k_assemble_nodes_staged<PRECOND, TD_ONLY, GG>), dim3(nblocks((int64_t)n * GG)), dim3(NT),                    \
+                                        (size_t)(NT / GG) * cmax * 3 * sizeof(double), ctx->stream, n, P, cmax, ctx->d_pair_ptr, ctx->d_pair_col,  \
+                                        ctx->d_node_side, ctx->d_pair_M, ctx->d_pair_K, ctx->d_contrib_ptr, ctx->d_contrib_slot, ctx->d_contrib_k, \
+                                        ctx->d_node_cell_ptr, ctx->d_node_cell, ctx->d_cbar, at, ac)
+        switch (ctx->asm_group) {
+            case 4: KNP_ASMS(4); break;
+            case 8: KNP_ASMS(8); break;
+            case 16: KNP_ASMS(16); break;
+            default: KNP_ASMS(32); break;
+        }
+#undef KNP_ASMS
+        return;
+    }
 #define KNP_ASM(GG) hipLaunchKernelGGL((k_assemble_nodes<PRECOND, TD_ONLY, GG>), dim3(nblocks((int64_t)n * GG)), dim3(NT), 0, ctx->stream, n, P, ctx->d_pair_ptr, \
                                        ctx->d_pair_col, ctx->d_node_side, ctx->d_pair_M, ctx->d_pair_K, ctx->d_contrib_ptr, ctx->d_contrib_cell,       \
                                        ctx->d_contrib_k, ctx->d_cbar, at, ac)
@@ -1781,8 +1880,22 @@ int knp_create(knp_ctx** out, const knp_mesh_desc* mesh) {
     KCHK(dev_upload(ctx, &ctx->d_pair_K, g.pair_K));
     KCHK(dev_upload(ctx, &ctx->d_contrib_ptr, g.contrib_ptr));
 
-    KCHK(dev_upload(ctx, &ctx->d_contrib_cell, g.contrib_cell));
     KCHK(dev_upload(ctx, &ctx->d_contrib_k, g.contrib_k));
+    {   // staged assembly: LDS for the cell means of every node of a block; 48 KB per block keeps >= 3 blocks per CU
+        const char* es = getenv("KNP_ASM_STAGE");
+        const bool want = !(es && atoi(es) == 0);
+        const double avg_deg0 = g.n_nodes_owned ? (double)g.pair_col.size() / g.n_nodes_owned : 1.0;
+        const int G0 = avg_deg0 <= 4.5 ? 4 : avg_deg0 <= 9.0 ? 8 : avg_deg0 <= 20.0 ? 16 : 32;
+        const size_t lds = (size_t)(NT / G0) * g.max_node_cells * 3 * sizeof(double);
+        if (want && g.max_node_cells > 0 && g.max_node_cells <= 255 && lds <= 48 * 1024) {
+            ctx->asm_stage = g.max_node_cells;
+            KCHK(dev_upload(ctx, &ctx->d_node_cell_ptr, g.node_cell_ptr));
+            KCHK(dev_upload(ctx, &ctx->d_node_cell, g.node_cell));
+            KCHK(dev_upload(ctx, &ctx->d_contrib_slot, g.contrib_slot));
+        } else {
+            KCHK(dev_upload(ctx, &ctx->d_contrib_cell, g.contrib_cell));
+        }
+    }
     KCHK(dev_upload(ctx, &ctx->d_fv, g.fv));
     KCHK(dev_upload(ctx, &ctx->d_fmeas, g.fmeas));
     KCHK(dev_upload_raw(ctx, &ctx->d_gamma_prog, mesh->gamma_prog, (size_t)g.n_g));
@@ -1847,7 +1960,7 @@ int knp_create(knp_ctx** out, const knp_mesh_desc* mesh) {
         if (e && atoi(e) > 0) ctx->spmv_group = atoi(e);
         ctx->asm_group = ctx->spmv_group;
         const char* ea = getenv("KNP_ASM_GROUP");
-        if (ea && atoi(ea) > 0) ctx->asm_group = atoi(ea);
+        if (ea && atoi(ea) > 0 && ctx->asm_stage == 0) ctx->asm_group = atoi(ea);   // (the staged variant sized its LDS for the default)
         // the level-0 preconditioner kernels move half the bytes per node pair (fp32 P, no cross block): fewer lanes per node
         ctx->pc_group = std::max(4, ctx->spmv_group / 2);
         const char* ep = getenv("KNP_PC_GROUP");
@@ -1873,6 +1986,8 @@ int knp_create(knp_ctx** out, const knp_mesh_desc* mesh) {
     // free the big host arrays that are no longer needed (pattern kept for export)
     std::vector<int32_t>().swap(g.contrib_cell);
     std::vector<double>().swap(g.contrib_k);
+    std::vector<int32_t>().swap(g.node_cell);
+    std::vector<uint8_t>().swap(g.contrib_slot);
     return KNP_OK;
 }
 
@@ -1891,6 +2006,7 @@ int knp_destroy(knp_ctx* ctx) {
     dev_free(ctx->d_pair_ptr); dev_free(ctx->d_pair_col); dev_free(ctx->d_pair_row);
     dev_free(ctx->d_pair_M); dev_free(ctx->d_pair_K);
     dev_free(ctx->d_contrib_ptr); dev_free(ctx->d_contrib_cell); dev_free(ctx->d_contrib_k);
+    dev_free(ctx->d_node_cell_ptr); dev_free(ctx->d_node_cell); dev_free(ctx->d_contrib_slot);
     dev_free(ctx->d_fv); dev_free(ctx->d_fmeas); dev_free(ctx->d_gamma_prog); dev_free(ctx->d_qp); dev_free(ctx->d_qw);
     dev_free(ctx->d_gv_vertex); dev_free(ctx->d_gv_node_i); dev_free(ctx->d_gv_node_e); dev_free(ctx->d_node_gv);
     dev_free(ctx->d_gptr); dev_free(ctx->d_gcol); dev_free(ctx->d_grow); dev_free(ctx->d_gq_i); dev_free(ctx->d_gq_e);
