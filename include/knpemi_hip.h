@@ -77,6 +77,9 @@ extern "C" {
 #define KNP_PC_AMG 2      /* multilevel V-cycle on P, hierarchy 0 = all fields (the reference's block-Jacobi form) */
 #define KNP_PC_AMG_BT 3   /* block lower-triangular: hierarchy 0 = ion fields, then the potential (hierarchy 1) on
                              r_phi - A_{phi,k} z_k with a Cahouet-Chabard Schur term psi/(sum z^2 k)/M_lumped added */
+#define KNP_PC_AMG_LT 4   /* the reference's P with use_block_jacobi=False (KNPEMIx_problem.py:720-722): P keeps the (phi,k) blocks
+                             dt z_j D_j K (= those of A); applied as the block forward substitution z_k = V_k r_k,
+                             z_phi = V_phi (r_phi - P_{phi,k} z_k) with the same two hierarchies, no Schur term */
 
 /* membrane-program opcodes: instruction = {op, dst, a, b}, registers are doubles */
 enum {

@@ -18,7 +18,7 @@ KNP_SZ_COUNT = 16
 (SZ_N_NODES, SZ_N_NODES_OWNED, SZ_N_DOF_LOCAL, SZ_N_DOF_OWNED, SZ_NNZ, SZ_N_PAIRS, SZ_N_CONTRIB,
  SZ_N_GAMMA_VERTS, SZ_N_GAMMA_PAIRS, SZ_NNZ_P, SZ_N_PHI_OWNED) = range(11)
 
-PC_NONE, PC_VBJACOBI, PC_AMG, PC_AMG_BT = 0, 1, 2, 3
+PC_NONE, PC_VBJACOBI, PC_AMG, PC_AMG_BT, PC_AMG_LT = 0, 1, 2, 3, 4
 
 OPS = dict(CONST=0, KI=1, KE=2, PHIM=3, AUX=4, X=5, ADD=6, SUB=7, MUL=8, DIV=9, NEG=10, POW=11, LN=12,
            EXP=13, SQRT=14, MAX=15, MIN=16, ABS=17, LT=18, GT=19, LE=20, GE=21, EQ=22, AND=23, OR=24,

@@ -701,9 +701,11 @@ class ProblemKNPEMI(MixedDimensionalProblem):
 
     def setup_preconditioner(self, use_block_jacobi: bool):
         self.print("Setting up preconditioner ...")
-        if not use_block_jacobi:
-            raise NotImplementedError("Only the block-Jacobi preconditioner form (KNPEMIx_problem.py:717-719) is implemented.")
-        self.P = "hard-wired in knp_kernels.hip (k_assemble_pairs<true>, k_gamma_pairs<true>)"
+        # use_block_jacobi=False (KNPEMIx_problem.py:720-722): the phi rows of P keep the -D grad k flux, i.e. P additionally has
+        # the (phi,k) blocks dt z_j D_j K -- exactly the (phi,k) blocks of A.  The diagonal blocks are the same either way; the
+        # solver then applies P as a block forward substitution (knp_pc_setup kind KNP_PC_AMG_LT) instead of block-diagonally.
+        self.P_block_jacobi = bool(use_block_jacobi)
+        self.P = "hard-wired in knp_kernels.hip (k_assemble_nodes<true>, k_gamma_pairs<true>)" + ("" if use_block_jacobi else " + (phi,k) blocks of A")
 
     def print_conservation(self):
         be = self.create_backend()

@@ -159,7 +159,11 @@ class SolverKNPEMI:
         self.print("Assembling preconditioner ...")
         be = self.backend
         be.assemble_precond()
-        if self._pc_kind in (_lib.PC_AMG, _lib.PC_AMG_BT):
+        if self._pc_kind in (_lib.PC_AMG, _lib.PC_AMG_BT) and not getattr(self.problem, "P_block_jacobi", True):
+            # the reference's non-block-Jacobi form of P: same diagonal blocks + the (phi,k) coupling, applied as a block forward
+            # substitution with the ion and potential hierarchies
+            self._pc_kind = _lib.PC_AMG_LT
+        if self._pc_kind in (_lib.PC_AMG, _lib.PC_AMG_BT, _lib.PC_AMG_LT):
             tic = time.perf_counter()
             be.check(be.lib.knp_amg_set_precision(be.ctx, 1 if self.amg_fp32 else 0))
             P = be.precond_csr()
@@ -205,7 +209,7 @@ class SolverKNPEMI:
         be = self.backend
         tic = time.perf_counter()
         halo0, start, ggid, gown = be.dof_level_halo()
-        specs = [((0, 1, 2, 3), 1)] if self._pc_kind == _lib.PC_AMG else [((0, 1, 2), 2), ((3,), 3)]
+        specs = [((0, 1, 2, 3), 1)] if self._pc_kind == _lib.PC_AMG else [((0, 1, 2), 2), ((3,), 3)]      # BT and LT: two hierarchies
         self.hierarchies = []
         for index, (fields, native_mode) in enumerate(specs):
             Pm = P_loc if len(fields) == 4 else dist_amg.restrict_to_fields_rect(P_loc, fields)
@@ -306,7 +310,7 @@ class SolverKNPEMI:
         be = self.backend
         self._sync()
         setup_timer += self.comm.allreduce_max(time.perf_counter() - tic)
-        if self.use_P_mat and self._pc_kind in (_lib.PC_AMG, _lib.PC_AMG_BT):
+        if self.use_P_mat and self._pc_kind in (_lib.PC_AMG, _lib.PC_AMG_BT, _lib.PC_AMG_LT):
             tic = time.perf_counter()
             p.setup_preconditioner(self.use_block_Jacobi)
             self.assemble_preconditioner()
@@ -337,7 +341,7 @@ class SolverKNPEMI:
             tic = time.perf_counter()
             self._b_is_final = i > 1          # step 1: the null-space projection still modifies b after the assembly
             self.assemble()
-            if i > 1 and self.reassemble_P and (i % self.reassemble_N == 0) and self.use_P_mat and self._pc_kind in (_lib.PC_AMG, _lib.PC_AMG_BT):
+            if i > 1 and self.reassemble_P and (i % self.reassemble_N == 0) and self.use_P_mat and self._pc_kind in (_lib.PC_AMG, _lib.PC_AMG_BT, _lib.PC_AMG_LT):
                 self.reassemble_preconditioner()
             self._sync()
             max_assembly_time = self.comm.allreduce_max(time.perf_counter() - tic)

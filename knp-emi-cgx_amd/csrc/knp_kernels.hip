@@ -749,11 +749,59 @@ static void launch_phi_rhs(knp_ctx* ctx, const double* r, const double* z, doubl
     }
 #undef KNP_PR
 }
+// Literal block lower-triangular form (the reference's P with use_block_jacobi=False, KNPEMIx_problem.py:720-722: the phi rows
+// of P keep their -D grad k flux, i.e. P_{phi,kj} = dt z_j D_j K = the (phi,k) block of A): t_phi = r_phi - P_{phi,k} z_k
+template <int G, bool COMPACT>
+__global__ void __launch_bounds__(NT)
+k_phi_rhs_literal(int n_nodes, const int32_t* __restrict__ pair_ptr, const int32_t* __restrict__ pair_col, const double* __restrict__ ac,
+                  const double* __restrict__ r, const double* __restrict__ z, double* __restrict__ t) {
+    const int node = (blockIdx.x * NT + threadIdx.x) / G;
+    const int lane = threadIdx.x & (G - 1);
+    double s = 0.0;
+    if (node < n_nodes) {
+        const int p0 = pair_ptr[node];
+        const int deg = pair_ptr[node + 1] - p0;
+        for (int q = lane; q < deg; q += G) {
+            const size_t p = (size_t)p0 + q;
+            const int nb = pair_col[p];
+            const double a0 = ac[6 * p + 3];
+            const double2 a12 = *reinterpret_cast<const double2*>(ac + 6 * p + 4);
+            const double2 za = *reinterpret_cast<const double2*>(z + 4 * (size_t)nb);
+            const double zc = z[4 * (size_t)nb + 2];
+            s += a0 * za.x + a12.x * za.y + a12.y * zc;
+        }
+    }
+#pragma unroll
+    for (int o = G >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, G);
+    if (lane == 0 && node < n_nodes) {
+        const size_t i = 4 * (size_t)node;
+        const double tphi = r[i + 3] - s;
+        if (COMPACT) {
+            t[node] = tphi;
+        } else {
+            *reinterpret_cast<double2*>(t + i) = make_double2(0.0, 0.0);
+            *reinterpret_cast<double2*>(t + i + 2) = make_double2(0.0, tphi);
+        }
+    }
+}
+template <bool COMPACT>
+static void launch_phi_rhs_literal(knp_ctx* ctx, const double* r, const double* z, double* t) {
+    const int n = ctx->g.n_nodes_owned, G = ctx->pc_group;
+    if (n <= 0) return;
+#define KNP_PL(GG) hipLaunchKernelGGL((k_phi_rhs_literal<GG, COMPACT>), dim3(nblocks((int64_t)n * GG)), dim3(NT), 0, ctx->stream, n, ctx->d_pair_ptr, ctx->d_pair_col, ctx->d_ac, r, z, t)
+    switch (G) {
+        case 4: KNP_PL(4); break;
+        case 8: KNP_PL(8); break;
+        case 16: KNP_PL(16); break;
+        default: KNP_PL(32); break;
+    }
+#undef KNP_PL
+}
 __global__ void __launch_bounds__(NT) k_schur_fin(int n_nodes, const double* __restrict__ cc, const double* __restrict__ t,
                                                   const double* __restrict__ w, double* __restrict__ z) {
     const int n = blockIdx.x * NT + threadIdx.x;
     if (n >= n_nodes) return;
-    z[(size_t)4 * n + 3] = w[(size_t)4 * n + 3] + cc[n] * t[(size_t)4 * n + 3];
+    z[(size_t)4 * n + 3] = w[(size_t)4 * n + 3] + (cc ? cc[n] * t[(size_t)4 * n + 3] : 0.0);
 }
 __global__ void __launch_bounds__(NT)
 k_schur_diag(int n_nodes, double psi, double z0, double z1, double z2, const int32_t* __restrict__ node_vertex,
@@ -989,7 +1037,7 @@ k_level_up(int n_act, const int32_t* __restrict__ rows, const int32_t* __restric
             ri = r[row];
             if (xin) x0 = xin[row];
             if (!xin || MODE == 1) bi = b[row];
-            if (MODE == 1) ci_ = cc[row];
+            if (MODE == 1 && cc) ci_ = cc[row];
         }
         s = row_dot4<L, VT>(k0, e, lane, ci, v, xc);
     }
@@ -3111,8 +3159,9 @@ static void amg_cycle_fused(knp_ctx* ctx, KnpAmgHier& H, const double* b, double
             else launch_level_up_t<double, 0>(st, L.S_lanes, n_act, L.S_n_act > 0 ? L.S_act_rows : nullptr, rp, L.S_ci, L.S_v, C.x, L.inv_diag, L.b, L.r, L.x, c, c, L.x, nullptr);
         } else if (phi) {
             const int32_t* rows = L.S_n_act > 0 ? L.S_act_rows_c : nullptr;
-            if (L.S_vf) launch_level_up_t<float, 1>(st, L.S_lanes, L.S_n_act > 0 ? n_act : nn, rows, rp, L.S_ci, L.S_vf, C.x, L.dinv_c, b, L.r, nullptr, c, c, z, ctx->d_cc);
-            else launch_level_up_t<double, 1>(st, L.S_lanes, L.S_n_act > 0 ? n_act : nn, rows, rp, L.S_ci, L.S_v, C.x, L.dinv_c, b, L.r, nullptr, c, c, z, ctx->d_cc);
+            const double* ccp = ctx->pc_kind == KNP_PC_AMG_LT ? nullptr : ctx->d_cc;   // no Schur term in the literal lower-triangular form
+            if (L.S_vf) launch_level_up_t<float, 1>(st, L.S_lanes, L.S_n_act > 0 ? n_act : nn, rows, rp, L.S_ci, L.S_vf, C.x, L.dinv_c, b, L.r, nullptr, c, c, z, ccp);
+            else launch_level_up_t<double, 1>(st, L.S_lanes, L.S_n_act > 0 ? n_act : nn, rows, rp, L.S_ci, L.S_v, C.x, L.dinv_c, b, L.r, nullptr, c, c, z, ccp);
         } else {
             if (L.S_vf) launch_level_up_t<float, 0>(st, L.S_lanes, n_act, L.S_n_act > 0 ? L.S_act_rows : nullptr, rp, L.S_ci, L.S_vf, C.x, L.inv_diag, b, L.r, nullptr, c, c, z, nullptr);
             else launch_level_up_t<double, 0>(st, L.S_lanes, n_act, L.S_n_act > 0 ? L.S_act_rows : nullptr, rp, L.S_ci, L.S_v, C.x, L.inv_diag, b, L.r, nullptr, c, c, z, nullptr);
@@ -3135,9 +3184,9 @@ static int check_hier(knp_ctx* ctx, int h) {
 int knp_pc_setup(knp_ctx* ctx, int32_t kind) {
     CHECK_CTX(ctx);
     side_discard(ctx);
-    if (kind != KNP_PC_NONE && kind != KNP_PC_VBJACOBI && kind != KNP_PC_AMG && kind != KNP_PC_AMG_BT) { ctx->err = "unknown pc kind"; return KNP_E_ARG; }
+    if (kind != KNP_PC_NONE && kind != KNP_PC_VBJACOBI && kind != KNP_PC_AMG && kind != KNP_PC_AMG_BT && kind != KNP_PC_AMG_LT) { ctx->err = "unknown pc kind"; return KNP_E_ARG; }
     if (kind == KNP_PC_AMG) KCHK(check_hier(ctx, 0));
-    if (kind == KNP_PC_AMG_BT) {
+    if (kind == KNP_PC_AMG_BT || kind == KNP_PC_AMG_LT) {
         KCHK(check_hier(ctx, 0));
         KCHK(check_hier(ctx, 1));
         if (!ctx->d_t2) {
@@ -3150,7 +3199,7 @@ int knp_pc_setup(knp_ctx* ctx, int32_t kind) {
     ctx->pc_kind = kind;
     for (int h = 0; h < KNP_MAX_HIER; ++h) ctx->hier[h].fused = 0;
     if (kind == KNP_PC_AMG) ctx->hier[0].fused = fused_eligible(ctx, ctx->hier[0]) ? 1 : 0;
-    if (kind == KNP_PC_AMG_BT) {   // both or none: the potential hierarchy then works on compact vectors
+    if (kind == KNP_PC_AMG_BT || kind == KNP_PC_AMG_LT) {   // both or none: the potential hierarchy then works on compact vectors
         const bool ok = fused_eligible(ctx, ctx->hier[0]) && fused_eligible(ctx, ctx->hier[1]) && ctx->hier[1].native0 == 3 && ctx->hier[0].native0 == 2 &&
                         ctx->hier[1].lv[0].S_n_act > 0 && ctx->hier[1].lv[0].S_act_rows_c && ctx->hier[1].lv[0].R_ci_c;
         ctx->hier[0].fused = ctx->hier[1].fused = ok ? 1 : 0;
@@ -3213,12 +3262,15 @@ static int pc_apply_proj(knp_ctx* ctx, const double* r, double* z, int64_t cnt) 
                 if (out != z) HIPCHK(hipMemcpyAsync(z, out, (size_t)ctx->n_dof_owned * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
                 break;
             }
-            case KNP_PC_AMG_BT: {
-                // z_k = V_k r_k ; t_phi = r_phi - A_{phi k} z_k ; z_phi = V_phi t_phi + cc * t_phi
+            case KNP_PC_AMG_BT:
+            case KNP_PC_AMG_LT: {
+                // z_k = V_k r_k ; t_phi = r_phi - A_{phi k} z_k ; z_phi = V_phi t_phi + cc * t_phi   (LT: literal coupling, no cc term)
+                const bool lit = ctx->pc_kind == KNP_PC_AMG_LT;
                 if (!ctx->have_A || !ctx->have_cc) { ctx->err = "block-triangular preconditioner needs an assembled matrix"; return KNP_E_STATE; }
                 if (ctx->hier[0].fused) {
                     amg_cycle_fused(ctx, ctx->hier[0], r, z);                 // ion entries of z
-                    launch_phi_rhs<true>(ctx, r, z, ctx->d_t2);               // t_phi on node-indexed vectors
+                    if (lit) launch_phi_rhs_literal<true>(ctx, r, z, ctx->d_t2);
+                    else launch_phi_rhs<true>(ctx, r, z, ctx->d_t2);          // t_phi on node-indexed vectors
                     if (ctx->n_bc > 0)
                         hipLaunchKernelGGL(k_bc_copy, dim3(nblocks(ctx->n_bc)), dim3(NT), 0, ctx->stream, ctx->n_bc, ctx->d_bc_dofs, r, ctx->d_t2, 2);
                     amg_cycle_fused(ctx, ctx->hier[1], ctx->d_t2, z);         // z_phi = V_phi t + cc t
@@ -3227,18 +3279,19 @@ static int pc_apply_proj(knp_ctx* ctx, const double* r, double* z, int64_t cnt) 
                 double* out = amg_vcycle(ctx, ctx->hier[0], 0, r, z);
                 if (out != z) HIPCHK(hipMemcpyAsync(z, out, (size_t)ctx->n_dof_owned * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
                 KCHK(halo_update(ctx, z));   // the mass-matrix row may reach ghost ion unknowns
-                launch_phi_rhs<false>(ctx, r, z, ctx->d_t2);
+                if (lit) launch_phi_rhs_literal<false>(ctx, r, z, ctx->d_t2);
+                else launch_phi_rhs<false>(ctx, r, z, ctx->d_t2);
                 if (ctx->n_bc > 0)   // pinned potentials: no Schur coupling, their right-hand side is the residual itself
                     hipLaunchKernelGGL(k_bc_copy, dim3(nblocks(ctx->n_bc)), dim3(NT), 0, ctx->stream, ctx->n_bc, ctx->d_bc_dofs, r, ctx->d_t2, 1);
                 double* w = amg_vcycle(ctx, ctx->hier[1], 0, ctx->d_t2, ctx->d_w2);
-                hipLaunchKernelGGL(k_schur_fin, dim3(nblocks(g.n_nodes_owned)), dim3(NT), 0, ctx->stream, g.n_nodes_owned, ctx->d_cc, ctx->d_t2, w, z);
+                hipLaunchKernelGGL(k_schur_fin, dim3(nblocks(g.n_nodes_owned)), dim3(NT), 0, ctx->stream, g.n_nodes_owned, lit ? (const double*)nullptr : ctx->d_cc, ctx->d_t2, w, z);
                 break;
             }
             default:
                 HIPCHK(hipMemcpyAsync(z, r, (size_t)ctx->n_dof_owned * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
                 break;
         }
-        if (ctx->n_bc > 0 && (ctx->pc_kind == KNP_PC_AMG || ctx->pc_kind == KNP_PC_AMG_BT))
+        if (ctx->n_bc > 0 && (ctx->pc_kind == KNP_PC_AMG || ctx->pc_kind == KNP_PC_AMG_BT || ctx->pc_kind == KNP_PC_AMG_LT))
             hipLaunchKernelGGL(k_bc_copy, dim3(nblocks(ctx->n_bc)), dim3(NT), 0, ctx->stream, ctx->n_bc, ctx->d_bc_dofs, r, z, 0);
         HIPCHK(hipGetLastError());
     }
@@ -3301,7 +3354,7 @@ static void side_discard(knp_ctx* ctx) {   // any call that could touch what the
 
 static bool exchanges_all_native(const knp_ctx* ctx) {
     if (!ctx->p2p || ctx->p2p_fine < 0 || ctx->p2p_red < 0 || ctx->defl_m > 0) return false;
-    const int nh = ctx->pc_kind == KNP_PC_AMG ? 1 : ctx->pc_kind == KNP_PC_AMG_BT ? 2 : 0;
+    const int nh = ctx->pc_kind == KNP_PC_AMG ? 1 : (ctx->pc_kind == KNP_PC_AMG_BT || ctx->pc_kind == KNP_PC_AMG_LT) ? 2 : 0;
     for (int h = 0; h < nh; ++h)
         for (int l = 0; l < ctx->hier[h].levels; ++l) {
             const KnpAmgLevel& L = ctx->hier[h].lv[l];

@@ -990,6 +990,31 @@ def pc_amg_vcycle_fused(levels, coarse_inv):
     return apply
 
 
+def pc_block_lower(o, hier_k, hier_p, pre=1, post=1, cheby_degree=2, fused=False):
+    """The reference's preconditioner matrix with ``use_block_jacobi=False`` (KNPEMIx_problem.py:720-722): P keeps the (phi,k)
+    blocks dt z_j D_j K, which are the (phi,k) blocks of A itself.  Applied the way the library applies it (KNP_PC_AMG_LT): block
+    forward substitution  z_k = V_k r_k ;  z_phi = V_phi (r_phi - P_{phi,k} z_k)  with the two hierarchies of the diagonal blocks."""
+    Vk = pc_amg_vcycle(hier_k.levels, hier_k.coarse_inv, pre, post, cheby_degree, fused=fused)
+    Vp = pc_amg_vcycle(hier_p.levels, hier_p.coarse_inv, pre, post, cheby_degree, fused=fused)
+    n = o.n_dof
+    pidx = np.arange(3, n, 4)
+    kmask = np.ones(n, dtype=bool)
+    kmask[pidx] = False
+
+    def apply(r):
+        A = o.current_A
+        z = Vk(r)
+        z[pidx] = 0.0
+        zk = np.where(kmask, z, 0.0)
+        t = np.zeros_like(r)
+        t[pidx] = r[pidx] - (A @ zk)[pidx] + 0.0          # only the (phi,k) blocks of A act on zk's ion entries ...
+        # ... but A's phi rows also hold (phi,phi) columns, which zk does not touch (its potential entries are zero)
+        w = Vp(t)
+        z[pidx] = w[pidx]
+        return z
+    return apply
+
+
 def pc_btcc(o, hier_k, hier_p, pre=1, post=1, cheby_degree=2, bc_dofs=None, fused=False):
     """NumPy restatement of the library's block lower-triangular preconditioner (KNP_PC_AMG_BT):
         z_k   = V_k r                                         (V-cycle of the ion-field hierarchy)

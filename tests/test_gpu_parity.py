@@ -454,3 +454,33 @@ def test_fused_cycle_is_the_same_operator_as_the_unfused_cycle(kind, N, pc, flag
     tol = 2e-6 if fp32 else 1e-12
     for f in range(4):
         assert np.max(np.abs(z1[f::4] - z0[f::4])) <= tol * np.max(np.abs(z0[f::4])), f
+
+
+@pytest.mark.parametrize("N,kind", [(24, "square"), (8, "cube")])
+def test_non_block_jacobi_form_of_P(N, kind, monkeypatch):
+    """``use_block_Jacobi = False`` (class switch of the reference's solver, KNPEMIx_solver.py:37; form KNPEMIx_problem.py:720-722):
+    P keeps the (phi,k) blocks of A and is applied as a block forward substitution.  Same iterations and iterates as the
+    oracle's restatement, and the converged answer is the sparse-LU one."""
+    import knpemi_oracle as K
+    from CGx.KNPEMI.KNPEMIx_solver import SolverKNPEMI
+    monkeypatch.setattr(SolverKNPEMI, "use_block_Jacobi", False)
+    cfg = ci_config(N=N, steps=2, rtol=1e-10, kind=kind)
+    cfg["solver"]["ksp_settings"]["amg_coarse_size"] = 150
+    cfg["solver"]["ksp_settings"]["ksp_max_it"] = 500
+    s = run_native(cfg)
+    assert all(r > 0 for r in s.reasons)
+    from cgx_hip import _lib
+    assert s._pc_kind == _lib.PC_AMG_LT and not s.problem.P_block_jacobi
+    hk, hp = s.hierarchies
+    fused = bool(s.backend.stats()["fused"])
+    hk, hp = fp32_stored(hk, coarse=fused), fp32_stored(hp)
+    o = make_oracle(N, kind)
+    xo, its = o.run(2, solver="gmres", rtol=1e-10, pc=lambda P: K.pc_block_lower(o, hk, hp, s.amg_pre, s.amg_post, s.amg_cheby_degree, fused=fused))
+    assert its == list(s.iterations)
+    x = s.backend.x.cpu().numpy()
+    for f in range(4):
+        assert np.max(np.abs(x[f::4] - xo[f::4])) <= 1e-8 * np.max(np.abs(xo[f::4])), f
+    ol = run_oracle(N=N, steps=2, kind=kind)
+    ni, _ = s.potential_norms()
+    oi, _ = ol.potential_norms()
+    assert abs(ni - oi) <= 1e-5 * oi
