@@ -17,8 +17,9 @@ Linear solver mapping (reference :211-214, 269-280):
   pc_type  bjacobi|vbjacobi-> per-vertex 4x4 / 8x8 block Jacobi of A (HIP)
   pc_type  none            -> unpreconditioned
   direct: True             -> MUMPS has no native counterpart; emulated by GMRES+AMG driven to
-                              rtol 1e-13 with the l2 gauge of the iterative path (the gauge constant
-                              therefore differs from MUMPS's, see tests/test_oracle_pins.py).
+                              rtol 1e-13, with the gauge of the reference's preonly/LU solve: zero mean over
+                              the potential unknowns (the solution is projected, as PETSc does with the
+                              attached null space; see tests/test_oracle_pins.py).
 Unlike the reference (which never checks ``ksp.getConvergedReason()``), non-convergence is recorded
 in ``self.reasons`` and raises when ``strict`` is set.
 """
@@ -243,7 +244,7 @@ class SolverKNPEMI:
         self.b = be.b
         self.x = be.x
         if self.direct_solver:
-            self.print("Direct solver requested: emulated natively by GMRES+AMG at rtol 1e-13 (no MUMPS on the GPU).")
+            self.print("Direct solver requested: emulated natively by GMRES+AMG at rtol 1e-13, zero-mean gauge (no MUMPS on the GPU).")
             self._pc_kind = _lib.PC_AMG
             self._rtol = 1e-13
         else:
@@ -374,6 +375,11 @@ class SolverKNPEMI:
             if reason < 0 and self.strict:
                 raise RuntimeError(f"GMRES did not converge at step {i}: {_lib.REASONS.get(reason, reason)}")
 
+            if self.direct_solver and not p.dirichlet_bcs and not p.pin_ecs_potential:
+                # preonly + LU with the null space attached (reference :167-172, :331-333): PETSc removes the null-space
+                # component from the SOLUTION, i.e. the potentials come back with zero mean over all potential unknowns --
+                # the gauge of the reference's direct-solver pins (tests/test_oracle_pins.py::test_direct_solver_pin_without_any_fit)
+                be.project_nullspace(be.x)
             be.unpack()                                # x -> wh, phi_m_prev = phi_i - phi_e (reference :452-468)
             if self.output is not None:
                 self.output.record(i)                  # reference :471-474 (checkpoint / trace / point evaluation)

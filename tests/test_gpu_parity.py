@@ -484,3 +484,17 @@ def test_non_block_jacobi_form_of_P(N, kind, monkeypatch):
     ni, _ = s.potential_norms()
     oi, _ = ol.potential_norms()
     assert abs(ni - oi) <= 1e-5 * oi
+
+
+def test_direct_solver_config_against_reference_pins():
+    """The reference's direct-solver CI test (configs/tests/electric_potential_norms_direct_solver.yaml: ``direct: True``, 10 steps):
+    natively GMRES+AMG at rtol 1e-13 with PETSc's gauge for a preonly/LU solve with an attached null space (solution projected:
+    zero-mean potentials).  Both saved norms (tests/KNPEMI/electric_potential_norms_direct_solver.py:55-56) within 1e-6."""
+    pin_i, pin_e = 2.6337161145147203e-08, 1.5258564901943312e-08
+    s = run_native(ci_config(N=32, steps=10, direct=True))
+    assert all(r > 0 for r in s.reasons)
+    ni, ne = s.potential_norms()
+    assert abs(ni - pin_i) <= 1e-6 * pin_i, (ni, pin_i)
+    assert abs(ne - pin_e) <= 1e-6 * pin_e, (ne, pin_e)
+    x = s.backend.x.cpu().numpy()
+    assert abs(x[3::4].sum()) <= 1e-12 * np.abs(x[3::4]).sum()

@@ -42,6 +42,19 @@ def test_direct_solver_pin_modulo_gauge(ci_run):
     assert abs(ne - PIN_DIRECT[1]) <= 1e-8 * PIN_DIRECT[1]
 
 
+def test_direct_solver_pin_without_any_fit(ci_run):
+    """The gauge of the reference's direct solve is not an artefact: with the null space attached PETSc removes the
+    null-space component from the SOLUTION of the preonly/LU solve (KNPEMIx_solver.py:167-172, 331-333), i.e. the potentials
+    have zero mean over all potential unknowns.  In that gauge BOTH saved norms of the direct-solver test
+    (tests/KNPEMI/electric_potential_norms_direct_solver.py:55-56, tolerance 1e-10 relative there) are reproduced to 3e-10."""
+    o, _ = ci_run
+    vi, ve = o.lay.node_i >= 0, o.lay.node_e >= 0
+    c = -(o.phi[0][vi].sum() + o.phi[1][ve].sum()) / (vi.sum() + ve.sum())
+    ni, ne = o.l2_norm(np.where(vi, o.phi[0] + c, 0.0), 0), o.l2_norm(np.where(ve, o.phi[1] + c, 0.0), 1)
+    assert abs(ni - PIN_DIRECT[0]) <= 1e-9 * PIN_DIRECT[0]
+    assert abs(ne - PIN_DIRECT[1]) <= 1e-9 * PIN_DIRECT[1]
+
+
 def test_iterative_solver_pin(ci_run):
     """phi_i meets the north-star tolerance (1e-6).  phi_e (1000x smaller) agrees to 1.2e-4, which is the
     linear-solver truncation error of the reference run itself -- see the noise-floor test below."""
