@@ -12,8 +12,9 @@ Pinning status
 * 2D (unit square): PINNED.  ``tests/test_oracle_pins.py`` reproduces the
   reference's own known answers
   (``tests/KNPEMI/electric_potential_norms_iterative_solver.py:58-59`` to the
-  reference's tolerance 1e-7 rel., and ``..._direct_solver.py:55-56`` modulo the
-  single gauge constant MUMPS picks).
+  reference's tolerance 1e-7 rel. on phi_i, and BOTH norms of ``..._direct_solver.py:55-56``
+  to 3e-10 in the zero-mean gauge PETSc gives a preonly/LU solve with an attached null space
+  -- no fitted constant).
 * 3D (unit cube): PINNED through the manufactured-solution path.  ``oracle/mms_oracle.py``
   restates the reference's MMS set-up on top of this file and reproduces the reference's
   recorded L2 errors (src/CGx/utils/errors.py:8-28) to 5 significant digits for the potentials on
