@@ -283,7 +283,7 @@ def main_case(args, world, rank, dist, torch):
     roof = roofline_block(be, run["prof"], args.workload, world)
     norms = solver.potential_norms()
     n_steps_timed = len(run["its"])
-    per_it = {k: run["stats"][k] / max(sum(run["its"]), 1) for k in ("allreduces", "halos", "readbacks")}
+    per_it = {k: run["stats"][k] / max(sum(run["its"]), 1) for k in ("allreduces", "halos", "readbacks", "norm_fallbacks")}
     out = {
         "metric": "MDoF/s per implicit timestep (assembly+GMRES)",
         "value": value, "unit": "MDoF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
