@@ -314,7 +314,7 @@ def main_case(args, world, rank, dist, torch):
         class _P:      # plain record: the device objects of this case can be freed
             pass
         sp_ = _P()
-        for k in ("amg_pre", "amg_post", "amg_cheby_degree", "amg_theta", "amg_coarse_size", "amg_fp32"):
+        for k in ("amg_pre", "amg_post", "amg_cheby_degree", "amg_theta", "amg_coarse_size", "amg_fp32", "amg_node_sync"):
             setattr(sp_, k, getattr(solver, k))
         sp_.fused = bool(be.stats()["fused"])
         info = {"case": {"kind": case["kind"], "N": case["N"], "pc": case["pc"]}, "solver": sp_, "snap": run["snap"]}
@@ -422,7 +422,8 @@ def cpu_baseline(case, args, solver, snap):
     def fac(P, wrap=lambda h: h):      # hierarchies are built once (host setup, like ksp.setUp()) and shared by both CPU legs
         if not built:
             if pc == "btcc":
-                built["k"] = rnd(amg.build_hierarchy(amg.restrict_to_fields(P, (0, 1, 2)), theta=solver.amg_theta, coarse_size=solver.amg_coarse_size), coarse=fused)
+                built["k"] = rnd(amg.build_hierarchy(amg.restrict_to_fields(P, (0, 1, 2)), theta=solver.amg_theta, coarse_size=solver.amg_coarse_size,
+                                                     node_fields=(4, (0, 1, 2)) if solver.amg_node_sync else None), coarse=fused)
                 built["p"] = rnd(amg.build_hierarchy(amg.restrict_to_fields(P, (3,)), theta=solver.amg_theta, coarse_size=solver.amg_coarse_size))
             else:
                 built["h"] = rnd(amg.build_hierarchy(P, theta=solver.amg_theta, coarse_size=solver.amg_coarse_size))

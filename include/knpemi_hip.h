@@ -240,6 +240,14 @@ int knp_set_deflation(knp_ctx* ctx, int32_t n_modes, const int32_t* node_mode, c
 /* AMG hierarchies (hier 0 or 1) supplied level by level (level 0 = finest = P itself, possibly restricted to a
  * field class by zero rows). All arrays HOST; copied. */
 int knp_amg_reset(knp_ctx* ctx, int32_t hier, int32_t n_levels, int32_t pre_sweeps, int32_t post_sweeps, int32_t cheby_degree);
+/* Optional, between knp_amg_reset and the levels: the hierarchy has nf (3 or 4) decoupled fields per node that share one
+ * sparsity pattern on every level (node-synchronised aggregation: level-0 unknowns 4*node + field, coarse unknowns
+ * nf*aggregate + field, rows sorted by column).  With fp32 storage the library then keeps node-blocked copies of the
+ * restrictors, the coarse level operators and S (one column index per node entry, nf values behind it) and the fused cycle
+ * runs on them.  The pattern is verified level by level; a level that does not have it keeps the whole hierarchy on the
+ * scalar kernels (KNP_ST_BLOCKED tells).  What PCGAMG/hypre reach with a block size of the matrix (MatSetBlockSize) for the
+ * reference's preconditioner matrix (KNPEMI/KNPEMIx_solver.py:78-101). */
+int knp_amg_set_node_fields(knp_ctx* ctx, int32_t hier, int32_t nf);
 int knp_amg_set_level(knp_ctx* ctx, int32_t hier, int32_t level, int32_t n_rows, int32_t n_cols_halo,
                       const int32_t* A_rowptr, const int32_t* A_colind, const double* A_vals,
                       const double* inv_diag, double lambda_max,
@@ -296,7 +304,8 @@ enum { KNP_ST_BNORM = 0 /* ||B b|| of the last solve */, KNP_ST_ALLREDUCE = 1 /*
        KNP_ST_HALO = 2 /* fine-level halo exchanges */, KNP_ST_READBACK = 3 /* host waits on a reduced value */,
        KNP_ST_FUSED = 4 /* bit h set: hierarchy h runs the fused V(1,1) cycle; bit 2+h: its level 0 runs fused inside the
                            level-by-level cycle (distributed hierarchies) */,
-       KNP_ST_NORM_FALLBACK = 5 /* GMRES iterations whose norm needed a second reduction (cancellation guard) */, KNP_ST_COUNT = 8 };
+       KNP_ST_NORM_FALLBACK = 5 /* GMRES iterations whose norm needed a second reduction (cancellation guard) */,
+       KNP_ST_BLOCKED = 6 /* bit h set: the fused cycle of hierarchy h runs on node-blocked operators */, KNP_ST_COUNT = 8 };
 int knp_get_stats(const knp_ctx* ctx, double* out /* host [KNP_ST_COUNT] */);
 
 #ifdef __cplusplus

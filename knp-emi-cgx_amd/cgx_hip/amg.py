@@ -140,6 +140,7 @@ class Hierarchy:
     def __init__(self, levels, coarse_inv):
         self.levels = levels
         self.coarse_inv = coarse_inv
+        self.node_fields = 0
 
     def describe(self):
         rows = [lv.A.shape[0] for lv in self.levels]
@@ -160,13 +161,31 @@ def restrict_to_fields(P: sp.csr_matrix, fields, block: int = 4) -> sp.csr_matri
     return out
 
 
+def _replicate_pattern(Sn: sp.csr_matrix, stride: int, fields, n_dof: int) -> sp.csr_matrix:
+    """node-level pattern Sn copied onto every field's unknowns: entry (stride*r + f, stride*c + f) for every (r, c) of Sn, f in fields"""
+    coo = Sn.tocoo()
+    rows = np.concatenate([stride * coo.row + f for f in fields])
+    cols = np.concatenate([stride * coo.col + f for f in fields])
+    out = sp.csr_matrix((np.ones(rows.size), (rows, cols)), shape=(n_dof, n_dof))
+    out.sort_indices()
+    return out
+
+
 def build_hierarchy(P: sp.csr_matrix, theta: float = 0.08, max_levels: int = 12, coarse_size: int = 2500,
-                    smooth_prolongator: bool = True, agg_distance=2) -> Hierarchy:
+                    smooth_prolongator: bool = True, agg_distance=2, node_fields=None) -> Hierarchy:
     """Rows with a zero diagonal are inactive: they get no aggregate (zero rows in the prolongator, zero inverse
-    diagonal in the smoother), so a field-restricted P yields a hierarchy of that field class only."""
+    diagonal in the smoother), so a field-restricted P yields a hierarchy of that field class only.
+
+    ``node_fields = (stride, fields)`` (several fields per node, unknown = stride*node + field, the fields decoupled and with the
+    same graph -- the three ion blocks of P): the aggregation is done ONCE, on the node graph of the first field, and every field
+    uses the same aggregates and the same strength pattern.  Prolongators, restrictors, S and all coarse operators then have
+    the same sparsity pattern for every field (coarse unknown = nf*aggregate + field index), which lets the library store one
+    column index per node entry with nf values behind it.  The hierarchy is still an ordinary list of scalar CSR levels."""
     A = sp.csr_matrix(P, dtype=np.float64)
     A.sort_indices()
     levels = []
+    sync = node_fields is not None and len(node_fields[1]) > 1
+    stride, fields = (int(node_fields[0]), tuple(int(f) for f in node_fields[1])) if sync else (1, (0,))
     while True:
         diag = A.diagonal()
         dinv = np.where(diag != 0.0, 1.0 / np.where(diag != 0.0, diag, 1.0), 0.0)
@@ -177,15 +196,32 @@ def build_hierarchy(P: sp.csr_matrix, theta: float = 0.08, max_levels: int = 12,
             break
         # strength threshold decays with the level (Galerkin operators of smoothed aggregation get denser and
         # their entries more uniform; a fixed threshold stalls the coarsening in 3D)
-        S = strength_graph(A, theta * 0.25 ** len(levels))
         active = diag != 0.0
-        if active.all():
-            agg, nagg = aggregate(S, seed=len(levels), distance=_dist(agg_distance, len(levels)))
-            rows_t = np.arange(n)
+        if sync:
+            # node graph of the first field; aggregates of nodes; every field follows them
+            nf = len(fields)
+            nn = n // stride
+            A0 = A[fields[0]::stride][:, fields[0]::stride].tocsr()
+            Sn = strength_graph(A0, theta * 0.25 ** len(levels))
+            act_n = active[fields[0]::stride]
+            ian = np.nonzero(act_n)[0]
+            if act_n.all():
+                agg_n, nagg_n = aggregate(Sn, seed=len(levels), distance=_dist(agg_distance, len(levels)))
+            else:
+                agg_n, nagg_n = aggregate(Sn[ian][:, ian].tocsr(), seed=len(levels), distance=_dist(agg_distance, len(levels)))
+            S = _replicate_pattern(Sn, stride, fields, n)
+            rows_t = np.concatenate([stride * ian + f for f in fields])
+            agg = np.concatenate([nf * agg_n + k for k in range(nf)])
+            nagg = nf * nagg_n
         else:
-            ia = np.nonzero(active)[0]
-            agg, nagg = aggregate(S[ia][:, ia].tocsr(), seed=len(levels), distance=_dist(agg_distance, len(levels)))
-            rows_t = ia
+            S = strength_graph(A, theta * 0.25 ** len(levels))
+            if active.all():
+                agg, nagg = aggregate(S, seed=len(levels), distance=_dist(agg_distance, len(levels)))
+                rows_t = np.arange(n)
+            else:
+                ia = np.nonzero(active)[0]
+                agg, nagg = aggregate(S[ia][:, ia].tocsr(), seed=len(levels), distance=_dist(agg_distance, len(levels)))
+                rows_t = ia
         if nagg >= 0.9 * rows_t.size:                         # coarsening stalled
             levels.append(Level(A, dinv, lam))
             break
@@ -211,8 +247,12 @@ def build_hierarchy(P: sp.csr_matrix, theta: float = 0.08, max_levels: int = 12,
         Ac.sort_indices()
         levels.append(Level(A, dinv, lam, Pm, R, post_smoothed_prolongator(A, dinv, lam, Pm, AP)))
         A = Ac
+        if sync:
+            stride, fields = len(fields), tuple(range(len(fields)))      # coarse unknowns: nf * aggregate + field index
     coarse_inv = dense_pseudo_inverse(levels[-1].A) if levels[-1].A.shape[0] <= 6000 else None
-    return Hierarchy(levels, coarse_inv)
+    h = Hierarchy(levels, coarse_inv)
+    h.node_fields = len(node_fields[1]) if sync else 0                   # > 0: same pattern for every field on every level
+    return h
 
 
 def dense_pseudo_inverse(A: sp.spmatrix) -> np.ndarray:
@@ -238,6 +278,12 @@ def upload(lib, ctx, check, hier: Hierarchy, pre: int = 1, post: int = 1, cheby_
 
     nl = len(hier.levels)
     check(lib.knp_amg_reset(ctx, index, nl, pre, post, cheby_degree))
+    if getattr(hier, "node_fields", 0) in (3, 4):      # node-synchronised: the library keeps node-blocked copies (rows sorted by column)
+        check(lib.knp_amg_set_node_fields(ctx, index, int(hier.node_fields)))
+        for lv in hier.levels:
+            for M in (lv.A, lv.R, getattr(lv, "S", None)):
+                if M is not None and not M.has_sorted_indices:
+                    M.sort_indices()
     keep = []
     for l, lv in enumerate(hier.levels):
         A = lv.A

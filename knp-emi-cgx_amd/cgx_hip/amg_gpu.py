@@ -177,12 +177,15 @@ def _aggregate(crow, col, n, seed, distance):
     return agg, nagg
 
 
-def build_hierarchy(P, theta: float = 0.08, max_levels: int = 12, coarse_size: int = 2500, agg_distance=2, device="cuda"):
-    """Device version of ``amg.build_hierarchy`` (same arguments, same kind of result)."""
+def build_hierarchy(P, theta: float = 0.08, max_levels: int = 12, coarse_size: int = 2500, agg_distance=2, device="cuda", node_fields=None):
+    """Device version of ``amg.build_hierarchy`` (same arguments, same kind of result; ``node_fields``: aggregation on the node
+    graph of the first field, shared by all fields -- see amg.build_hierarchy)."""
     A = _from_scipy(P, device)
     A_host = sp.csr_matrix(P, dtype=np.float64)
     A_host.sort_indices()
     levels = []
+    sync = node_fields is not None and len(node_fields[1]) > 1
+    stride, fields = (int(node_fields[0]), tuple(int(f) for f in node_fields[1])) if sync else (1, (0,))
     while True:
         n = A.shape[0]
         diag = A.diagonal()
@@ -194,20 +197,47 @@ def build_hierarchy(P, theta: float = 0.08, max_levels: int = 12, coarse_size: i
             levels.append(amg.Level(A_host, dinv.cpu().numpy(), lam))
             break
         th = theta * 0.25 ** len(levels)
-        skey = _strength(A, th)
-        # aggregation on the active sub-graph
-        ia = torch.nonzero(active).squeeze(1)
-        if n_act == n:
-            crow_s, col_s = _pattern_csr(skey, n)
-            agg, nagg = _aggregate(crow_s, col_s, n, len(levels), amg._dist(agg_distance, len(levels)))
+        if sync:
+            # node graph of the first field -> aggregates of nodes -> the same aggregates and strength pattern for every field
+            nf, nn, f0 = len(fields), n // stride, fields[0]
+            r_, c_, v_ = A.rows(), A.col, A.val
+            m0 = (r_ % stride == f0) & (c_ % stride == f0)
+            A0 = _from_coo(torch.div(r_[m0], stride, rounding_mode="floor"), torch.div(c_[m0], stride, rounding_mode="floor"), v_[m0], (nn, nn))
+            skey_n = _strength(A0, th)
+            act_n = active[f0::stride]
+            ian = torch.nonzero(act_n).squeeze(1)
+            n_act_n = int(ian.numel())
+            if n_act_n == nn:
+                crow_s, col_s = _pattern_csr(skey_n, nn)
+                agg_n, nagg_n = _aggregate(crow_s, col_s, nn, len(levels), amg._dist(agg_distance, len(levels)))
+            else:
+                newid = torch.cumsum(act_n.to(torch.int64), 0) - 1
+                rr = torch.div(skey_n, nn, rounding_mode="floor")
+                cc = skey_n - rr * nn
+                both = act_n[rr] & act_n[cc]
+                crow_s, col_s = _pattern_csr(newid[rr[both]] * n_act_n + newid[cc[both]], n_act_n)
+                agg_n, nagg_n = _aggregate(crow_s, col_s, n_act_n, len(levels), amg._dist(agg_distance, len(levels)))
+            rn = torch.div(skey_n, nn, rounding_mode="floor")
+            cn = skey_n - rn * nn
+            skey = torch.sort(torch.cat([(stride * rn + f) * n + (stride * cn + f) for f in fields]))[0]
+            ia = torch.cat([stride * ian + f for f in fields])
+            agg = torch.cat([nf * agg_n + k for k in range(nf)])
+            nagg = nf * nagg_n
         else:
-            newid = torch.cumsum(active.to(torch.int64), 0) - 1
-            rr = torch.div(skey, n, rounding_mode="floor")
-            cc = skey - rr * n
-            both = active[rr] & active[cc]
-            sub = newid[rr[both]] * n_act + newid[cc[both]]
-            crow_s, col_s = _pattern_csr(sub, n_act)
-            agg, nagg = _aggregate(crow_s, col_s, n_act, len(levels), amg._dist(agg_distance, len(levels)))
+            skey = _strength(A, th)
+            # aggregation on the active sub-graph
+            ia = torch.nonzero(active).squeeze(1)
+            if n_act == n:
+                crow_s, col_s = _pattern_csr(skey, n)
+                agg, nagg = _aggregate(crow_s, col_s, n, len(levels), amg._dist(agg_distance, len(levels)))
+            else:
+                newid = torch.cumsum(active.to(torch.int64), 0) - 1
+                rr = torch.div(skey, n, rounding_mode="floor")
+                cc = skey - rr * n
+                both = active[rr] & active[cc]
+                sub = newid[rr[both]] * n_act + newid[cc[both]]
+                crow_s, col_s = _pattern_csr(sub, n_act)
+                agg, nagg = _aggregate(crow_s, col_s, n_act, len(levels), amg._dist(agg_distance, len(levels)))
         if nagg >= 0.9 * n_act:
             levels.append(amg.Level(A_host, dinv.cpu().numpy(), lam))
             break
@@ -245,8 +275,12 @@ def build_hierarchy(P, theta: float = 0.08, max_levels: int = 12, coarse_size: i
         levels.append(amg.Level(A_host, dinv.cpu().numpy(), lam, Pm.scipy(), R.scipy(), S.scipy()))
         A = Ac
         A_host = Ac.scipy()
+        if sync:
+            stride, fields = len(fields), tuple(range(len(fields)))
     # the dense pseudo-inverse stays on the host (LAPACK): the device eigen-solver is not accurate enough for the nearly
     # singular potential block (residual |A A+ A - A| of 0.2-0.4 instead of 1e-13 on MI355X / ROCm 7.2)
     last = levels[-1].A
     coarse_inv = amg.dense_pseudo_inverse(last) if last.shape[0] <= 6000 else None
-    return amg.Hierarchy(levels, coarse_inv)
+    h = amg.Hierarchy(levels, coarse_inv)
+    h.node_fields = len(node_fields[1]) if sync else 0
+    return h

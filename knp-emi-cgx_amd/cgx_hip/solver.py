@@ -83,6 +83,7 @@ class SolverKNPEMI:
     amg_coarse_size = 2500
     amg_replicate_below = 300000
     amg_fp32 = True        # mixed-precision preconditioner storage (operators fp32, vectors/Krylov fp64)
+    amg_node_sync = True   # ion hierarchy: aggregate NODES once, all three ion fields share aggregates and sparsity patterns
     _b_is_final = False
     amg_setup = "gpu"      # where the hierarchy is built: "gpu" (torch sparse products, cgx_hip/amg_gpu.py) | "host" (SciPy)
 
@@ -116,7 +117,7 @@ class SolverKNPEMI:
             if "ksp_max_it" in ks: self.ksp_max_it = int(ks["ksp_max_it"])
             if "gmres_restart" in ks: self.gmres_restart = int(ks["gmres_restart"])
             if "strict" in ks: self.strict = bool(ks["strict"])
-            for k in ("amg_theta", "amg_cheby_degree", "amg_pre", "amg_post", "amg_coarse_size", "amg_replicate_below", "amg_fp32", "amg_setup"):
+            for k in ("amg_theta", "amg_cheby_degree", "amg_pre", "amg_post", "amg_coarse_size", "amg_replicate_below", "amg_fp32", "amg_setup", "amg_node_sync"):
                 if k in ks: setattr(self, k, type(getattr(self, k))(ks[k]))
         if self.ksp_type != "gmres":
             raise NotImplementedError(f"ksp_type '{self.ksp_type}': only 'gmres' is implemented natively.")
@@ -173,18 +174,18 @@ class SolverKNPEMI:
                 self.P_ = "device CSR (see Backend.precond_csr)"
                 return
             P = P[:, :be.n_dof_owned].tocsr()          # per-rank block (block-Jacobi across GPUs)
-            host_build = lambda M: amg.build_hierarchy(M, theta=self.amg_theta, coarse_size=self.amg_coarse_size)
+            host_build = lambda M, nf=None: amg.build_hierarchy(M, theta=self.amg_theta, coarse_size=self.amg_coarse_size, node_fields=nf)
             if str(self.amg_setup) == "gpu":
                 from . import amg_gpu
 
-                def build(M):
+                def build(M, nf=None):
                     # the setup is host logic either way (the V-cycle always runs in the library): if torch's sparse
                     # products are not usable on this installation, build the same hierarchy with SciPy
                     try:
-                        return amg_gpu.build_hierarchy(M, theta=self.amg_theta, coarse_size=self.amg_coarse_size, device=be.device)
+                        return amg_gpu.build_hierarchy(M, theta=self.amg_theta, coarse_size=self.amg_coarse_size, device=be.device, node_fields=nf)
                     except (RuntimeError, NotImplementedError) as exc:
                         self.print(f"device-side AMG setup unavailable ({type(exc).__name__}: {exc}); using the host setup")
-                        return host_build(M)
+                        return host_build(M, nf)
             else:
                 build = host_build
             if self._pc_kind == _lib.PC_AMG:
@@ -193,7 +194,7 @@ class SolverKNPEMI:
                 be.check(be.lib.knp_amg_use_native_level0(be.ctx, 0, 1))   # level 0 is the library's own P
                 self.hierarchies = [self.hierarchy]
             else:
-                hk = build(amg.restrict_to_fields(P, (0, 1, 2)))
+                hk = build(amg.restrict_to_fields(P, (0, 1, 2)), self.ion_node_fields())
                 hp = build(amg.restrict_to_fields(P, (3,)))
                 amg.upload(be.lib, be.ctx, be.check, hk, self.amg_pre, self.amg_post, self.amg_cheby_degree, index=0)
                 amg.upload(be.lib, be.ctx, be.check, hp, self.amg_pre, self.amg_post, self.amg_cheby_degree, index=1)
@@ -204,6 +205,10 @@ class SolverKNPEMI:
             self.amg_setup_time = time.perf_counter() - tic
             self.print(f"AMG hierarchies: {[h.describe() for h in self.hierarchies]} (host setup {self.amg_setup_time:0.3f} s)")
         self.P_ = "device CSR (see Backend.precond_csr)"
+
+    def ion_node_fields(self):
+        """``node_fields`` of the ion hierarchy (amg.build_hierarchy): the three ion blocks of P have the same graph"""
+        return (4, (0, 1, 2)) if self.amg_node_sync else None
 
     def _assemble_distributed_amg(self, P_loc):
         """Multi-GPU: one global smoothed-aggregation hierarchy (cgx_hip/dist_amg.py) instead of per-GPU blocks."""

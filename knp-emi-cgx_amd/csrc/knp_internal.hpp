@@ -103,6 +103,18 @@ int knp_p2p_allreduce(knp_ctx* ctx, int plan, double* v, int n, double* mirror, 
 int knp_p2p_check(knp_ctx* ctx);
 void knp_p2p_free(knp_ctx* ctx);
 
+// Node-blocked CSR of a hierarchy whose nf fields per node are decoupled and share one sparsity pattern (node-synchronised
+// aggregation, cgx_hip/amg.py build_hierarchy(node_fields=...)): one column NODE per entry, nf values behind it.  16 B per entry
+// for nf == 3 ({v0, v1, v2, column} in one float4) instead of 3 x (4 B column + 4 B value), and one gather of nf consecutive
+// unknowns instead of nf separate ones.  fp32 values only (mixed-precision preconditioner storage).
+struct KnpBlockedCsr {
+    int n_rows = 0;          // node rows
+    int32_t* rp = nullptr;   // [n_rows + 1]
+    float4* ev = nullptr;    // nf == 3: {v0, v1, v2, bit pattern of the column node}; nf == 4: {v0, v1, v2, v3}
+    int32_t* ci = nullptr;   // nf == 4 only
+    int lanes = 4;
+};
+
 struct KnpAmgLevel {
     int n = 0, n_coarse = 0;
     int n_loc = 0;   // local columns = owned + ghost (== n on one GPU)
@@ -132,6 +144,7 @@ struct KnpAmgLevel {
     // level 0 of a potential-only hierarchy on compact vectors [n_nodes]: node indices instead of 4*node+3
     int32_t *R_ci_c = nullptr, *S_act_rows_c = nullptr;
     double* dinv_c = nullptr;
+    KnpBlockedCsr bA, bR, bS;   // node-blocked copies (hierarchies with node_nf > 0, fp32 storage): level operator, restrictor, S
 };
 
 #define KNP_MAX_HIER 2
@@ -145,6 +158,8 @@ struct KnpAmgHier {
     // fused V(1,1) cycle (knp_pc_setup decides): Pt = P Dinv of level 0, fp64 or fp32, 4 fields per pair; potential part compact
     int fused = 0;
     int l0_fused = 0;   // level 0 in fused form inside the level-by-level cycle (distributed hierarchies)
+    int node_nf = 0;    // > 0: fields per node with identical patterns on every level (knp_amg_set_node_fields)
+    int blocked = 0;    // the fused cycle runs on the node-blocked copies (knp_pc_setup decides)
     double *pt = nullptr, *pt_phi = nullptr;
     float *pt_f = nullptr, *pt_phi_f = nullptr;
 };

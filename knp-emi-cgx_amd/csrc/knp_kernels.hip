@@ -1067,6 +1067,176 @@ static void launch_level_up_t(hipStream_t st, int lanes, int n_act, const int32_
 #undef KNP_UP
 }
 
+// ------------------------------------------------------------------------------------------
+// Node-blocked legs of the fused cycle (KnpBlockedCsr): the NF fields of a node are decoupled and share one pattern, so a
+// row is a NODE: one float4 per entry ({v0, v1, v2, column} for NF == 3), one gather of NF consecutive unknowns, NF sums per
+// lane.  XS = unknowns per column node in x (4 on level 0, where vectors hold four unknowns per node; NF on coarse levels).
+// ------------------------------------------------------------------------------------------
+template <int NF, int XS>
+__device__ __forceinline__ void bload_x(const double* __restrict__ x, int j, double xv[4]) {
+    const double* __restrict__ p = x + (size_t)XS * j;
+    if (XS == 4) {   // 32 B aligned
+        const double2 a = *reinterpret_cast<const double2*>(p);
+        const double2 b = *reinterpret_cast<const double2*>(p + 2);
+        xv[0] = a.x; xv[1] = a.y; xv[2] = b.x; xv[3] = b.y;
+    } else {
+        xv[0] = p[0]; xv[1] = p[1]; xv[2] = p[2];
+        xv[3] = NF == 4 ? p[3] : 0.0;
+    }
+}
+// two predicated entries in flight per lane (each: 16 B entry + 24/32 B gather)
+template <int L, int NF, int XS>
+__device__ __forceinline__ void brow_dot(int k0, int e, int lane, const float4* __restrict__ ev, const int32_t* __restrict__ ci,
+                                         const double* __restrict__ x, double s[4]) {
+    for (int q = k0 + lane; q < e; q += 2 * L) {
+        const int q2 = min(q + L, e - 1);
+        const bool h2 = q + L < e;
+        const float4 a = ev[q], b = ev[q2];
+        const int ja = NF == 3 ? __float_as_int(a.w) : ci[q];
+        const int jb = NF == 3 ? __float_as_int(b.w) : ci[q2];
+        double xa[4], xb[4];
+        bload_x<NF, XS>(x, ja, xa);
+        bload_x<NF, XS>(x, jb, xb);
+        s[0] += (double)a.x * xa[0];
+        s[1] += (double)a.y * xa[1];
+        s[2] += (double)a.z * xa[2];
+        if (NF == 4) s[3] += (double)a.w * xa[3];
+        if (h2) {
+            s[0] += (double)b.x * xb[0];
+            s[1] += (double)b.y * xb[1];
+            s[2] += (double)b.z * xb[2];
+            if (NF == 4) s[3] += (double)b.w * xb[3];
+        }
+    }
+}
+template <int L, int NF>
+__device__ __forceinline__ void breduce(double s[4]) {
+#pragma unroll
+    for (int o = L >> 1; o > 0; o >>= 1) {
+        s[0] += __shfl_xor(s[0], o, L);
+        s[1] += __shfl_xor(s[1], o, L);
+        s[2] += __shfl_xor(s[2], o, L);
+        if (NF == 4) s[3] += __shfl_xor(s[3], o, L);
+    }
+}
+// b_c = R r  [; d_c = x_c = c Dinv_c b_c when dinv is given]          rows: coarse nodes (NF unknowns each)
+template <int L, int NF, int XS>
+__global__ void __launch_bounds__(NT)
+k_brestrict(int n_rows, const int32_t* __restrict__ rp, const float4* __restrict__ ev, const int32_t* __restrict__ ci,
+            const double* __restrict__ x, double* __restrict__ y, double c, const double* __restrict__ dinv,
+            double* __restrict__ d, double* __restrict__ xo) {
+    const int row = (blockIdx.x * NT + threadIdx.x) / L;
+    const int lane = threadIdx.x & (L - 1);
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    if (row < n_rows) brow_dot<L, NF, XS>(rp[row], rp[row + 1], lane, ev, ci, x, s);
+    breduce<L, NF>(s);
+    if (lane == 0 && row < n_rows) {
+        const size_t i = (size_t)NF * row;
+#pragma unroll
+        for (int k = 0; k < NF; ++k) {
+            y[i + k] = s[k];
+            if (dinv) {
+                const double t = c * dinv[i + k] * s[k];
+                d[i + k] = t;
+                xo[i + k] = t;
+            }
+        }
+    }
+}
+// r = b - A x on a coarse level (NF unknowns per node in every vector)
+template <int L, int NF>
+__global__ void __launch_bounds__(NT)
+k_bresidual(int n_rows, const int32_t* __restrict__ rp, const float4* __restrict__ ev, const int32_t* __restrict__ ci,
+            const double* __restrict__ x, const double* __restrict__ b, double* __restrict__ y) {
+    const int row = (blockIdx.x * NT + threadIdx.x) / L;
+    const int lane = threadIdx.x & (L - 1);
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    double bv[4] = {0.0, 0.0, 0.0, 0.0};
+    if (row < n_rows) {
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < NF; ++k) bv[k] = b[(size_t)NF * row + k];
+        }
+        brow_dot<L, NF, NF>(rp[row], rp[row + 1], lane, ev, ci, x, s);
+    }
+    breduce<L, NF>(s);
+    if (lane == 0 && row < n_rows) {
+#pragma unroll
+        for (int k = 0; k < NF; ++k) y[(size_t)NF * row + k] = bv[k] - s[k];
+    }
+}
+// z = x0 + c2 Dinv r + S xc for the NF unknowns of every node row; x0 = xin when given, else c Dinv b.  RS = unknowns per ROW node
+// in dinv, b, r, xin, z (4 on level 0 -- the fourth one, the potential, is not touched when NF == 3)
+template <int L, int NF, int RS>
+__global__ void __launch_bounds__(NT)
+k_blevel_up(int n_rows, const int32_t* __restrict__ rp, const float4* __restrict__ ev, const int32_t* __restrict__ ci,
+            const double* __restrict__ xc, const double* __restrict__ dinv, const double* __restrict__ b, const double* __restrict__ r,
+            const double* xin, double c, double c2, double* z) {
+    const int row = (blockIdx.x * NT + threadIdx.x) / L;
+    const int lane = threadIdx.x & (L - 1);
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    double di[4], ri[4], x0[4];
+    if (row < n_rows) {
+        if (lane == 0) {   // the epilogue's operands travel together with the gathers
+            const size_t i = (size_t)RS * row;
+#pragma unroll
+            for (int k = 0; k < NF; ++k) {
+                di[k] = dinv[i + k];
+                ri[k] = r[i + k];
+                x0[k] = xin ? xin[i + k] : c * di[k] * b[i + k];
+            }
+        }
+        brow_dot<L, NF, NF>(rp[row], rp[row + 1], lane, ev, ci, xc, s);
+    }
+    breduce<L, NF>(s);
+    if (lane == 0 && row < n_rows) {
+        const size_t i = (size_t)RS * row;
+#pragma unroll
+        for (int k = 0; k < NF; ++k) z[i + k] = x0[k] + c2 * di[k] * ri[k] + s[k];
+    }
+}
+#define KNP_BL_SWITCH(LANES, CALL) \
+    switch (LANES) {               \
+        case 2: CALL(2); break;    \
+        case 4: CALL(4); break;    \
+        case 8: CALL(8); break;    \
+        case 16: CALL(16); break;  \
+        default: CALL(32); break;  \
+    }
+template <int NF, int XS>
+static void launch_brestrict_t(hipStream_t st, const KnpBlockedCsr& M, const double* x, double* y, double c, const double* dinv, double* d, double* xo) {
+    if (M.n_rows <= 0) return;
+#define KNP_BR(LL) hipLaunchKernelGGL((k_brestrict<LL, NF, XS>), dim3(nblocks((int64_t)M.n_rows * LL)), dim3(NT), 0, st, M.n_rows, M.rp, M.ev, M.ci, x, y, c, dinv, d, xo)
+    KNP_BL_SWITCH(M.lanes, KNP_BR)
+#undef KNP_BR
+}
+static void launch_brestrict(hipStream_t st, int nf, int xs, const KnpBlockedCsr& M, const double* x, double* y, double c, const double* dinv, double* d, double* xo) {
+    if (nf == 4) launch_brestrict_t<4, 4>(st, M, x, y, c, dinv, d, xo);
+    else if (xs == 4) launch_brestrict_t<3, 4>(st, M, x, y, c, dinv, d, xo);
+    else launch_brestrict_t<3, 3>(st, M, x, y, c, dinv, d, xo);
+}
+template <int NF>
+static void launch_bresidual_t(hipStream_t st, const KnpBlockedCsr& M, const double* x, const double* b, double* y) {
+    if (M.n_rows <= 0) return;
+#define KNP_BA(LL) hipLaunchKernelGGL((k_bresidual<LL, NF>), dim3(nblocks((int64_t)M.n_rows * LL)), dim3(NT), 0, st, M.n_rows, M.rp, M.ev, M.ci, x, b, y)
+    KNP_BL_SWITCH(M.lanes, KNP_BA)
+#undef KNP_BA
+}
+template <int NF, int RS>
+static void launch_blevel_up_t(hipStream_t st, const KnpBlockedCsr& M, const double* xc, const double* dinv, const double* b, const double* r,
+                               const double* xin, double c, double c2, double* z) {
+    if (M.n_rows <= 0) return;
+#define KNP_BU(LL) hipLaunchKernelGGL((k_blevel_up<LL, NF, RS>), dim3(nblocks((int64_t)M.n_rows * LL)), dim3(NT), 0, st, M.n_rows, M.rp, M.ev, M.ci, xc, dinv, b, r, xin, c, c2, z)
+    KNP_BL_SWITCH(M.lanes, KNP_BU)
+#undef KNP_BU
+}
+static void launch_blevel_up(hipStream_t st, int nf, int rs, const KnpBlockedCsr& M, const double* xc, const double* dinv, const double* b, const double* r,
+                             const double* xin, double c, double c2, double* z) {
+    if (nf == 4) launch_blevel_up_t<4, 4>(st, M, xc, dinv, b, r, xin, c, c2, z);
+    else if (rs == 4) launch_blevel_up_t<3, 4>(st, M, xc, dinv, b, r, xin, c, c2, z);
+    else launch_blevel_up_t<3, 3>(st, M, xc, dinv, b, r, xin, c, c2, z);
+}
+
 // setup helpers of the fused cycle
 //   Pt = P Dinv (pair-major, 4 fields per pair) and its compact potential part
 template <typename VT>
@@ -2666,6 +2836,67 @@ int knp_nullspace_test(knp_ctx* ctx, double* out_norm) {
 }
 
 // ---- AMG ---------------------------------------------------------------------------------
+static void free_blocked(KnpBlockedCsr& M) {
+    dev_free(M.rp); dev_free(M.ev); dev_free(M.ci);
+    M.n_rows = 0;
+}
+// Node-blocked copy of a scalar CSR whose rows come in groups of rs per row node (fields 0..nf-1 used, the others empty) and whose
+// columns are cs*node + field, when every field of a node row has the same column nodes in the same order (sorted rows).  The
+// pattern is VERIFIED here; a matrix that does not have it is left without a blocked copy (out->rp == nullptr) and the cycle
+// stays on the scalar kernels.
+static int build_blocked(knp_ctx* ctx, int nf, int n_rows_scalar, int rs, int cs, const int32_t* rp, const int32_t* ci, const double* v,
+                         KnpBlockedCsr* out) {
+    free_blocked(*out);
+    if ((nf != 3 && nf != 4) || rs < nf || cs < nf || n_rows_scalar <= 0 || n_rows_scalar % rs != 0) return KNP_OK;
+    const int nn = n_rows_scalar / rs;
+    std::vector<int32_t> brp((size_t)nn + 1, 0);
+    for (int i = 0; i < nn; ++i) {
+        const int r0 = rs * i;
+        const int cnt = rp[r0 + 1] - rp[r0];
+        for (int k = 1; k < rs; ++k)
+            if (rp[r0 + k + 1] - rp[r0 + k] != (k < nf ? cnt : 0)) return KNP_OK;
+        brp[(size_t)i + 1] = brp[i] + cnt;
+    }
+    const int64_t nnz = brp[nn];
+    std::vector<float4> ev((size_t)nnz);
+    std::vector<int32_t> bci(nf == 4 ? (size_t)nnz : 0);
+    for (int i = 0; i < nn; ++i) {
+        const int r0 = rs * i;
+        const int cnt = brp[(size_t)i + 1] - brp[i];
+        for (int q = 0; q < cnt; ++q) {
+            const int c0 = ci[rp[r0] + q];
+            if (c0 % cs != 0) return KNP_OK;
+            const int j = c0 / cs;
+            float val[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < nf; ++k) {
+                const int64_t e = (int64_t)rp[r0 + k] + q;
+                if (ci[e] != cs * j + k) return KNP_OK;
+                val[k] = (float)v[e];
+            }
+            float4 t;
+            t.x = val[0]; t.y = val[1]; t.z = val[2];
+            if (nf == 4) { t.w = val[3]; bci[(size_t)brp[i] + q] = j; }
+            else { int32_t jj = j; float w; memcpy(&w, &jj, 4); t.w = w; }
+            ev[(size_t)brp[i] + q] = t;
+        }
+    }
+    KCHK(dev_upload(ctx, &out->rp, brp));
+    KCHK(dev_upload(ctx, &out->ev, ev));
+    if (nf == 4) KCHK(dev_upload(ctx, &out->ci, bci));
+    out->n_rows = nn;
+    static const double scale = getenv("KNP_LANE_SCALE_B") ? atof(getenv("KNP_LANE_SCALE_B")) : 1.0;
+    const double avg = scale * (double)nnz / nn;   // two entries in flight per lane
+    out->lanes = avg <= 6.0 ? 2 : avg <= 12.0 ? 4 : avg <= 28.0 ? 8 : avg <= 64.0 ? 16 : 32;
+    return KNP_OK;
+}
+int knp_amg_set_node_fields(knp_ctx* ctx, int32_t hier, int32_t nf) {
+    CHECK_CTX(ctx);
+    if (hier < 0 || hier >= KNP_MAX_HIER || (nf != 0 && nf != 3 && nf != 4)) { ctx->err = "node fields: 0 (off), 3 or 4"; return KNP_E_ARG; }
+    KnpAmgHier& H = ctx->hier[hier];
+    if (H.levels < 1 || H.lv[0].n > 0) { ctx->err = "knp_amg_set_node_fields comes after knp_amg_reset and before the levels"; return KNP_E_STATE; }
+    H.node_nf = nf;
+    return KNP_OK;
+}
 static void free_hier(KnpAmgHier& H) {
     for (int l = 0; l < KNP_MAX_AMG_LEVELS; ++l) {
         KnpAmgLevel& L = H.lv[l];
@@ -2675,12 +2906,13 @@ static void free_hier(KnpAmgHier& H) {
         dev_free(L.x); dev_free(L.b); dev_free(L.r); dev_free(L.d); dev_free(L.r2);
         dev_free(L.S_rp); dev_free(L.S_ci); dev_free(L.S_v); dev_free(L.S_vf); dev_free(L.S_act_rows); dev_free(L.S_act_rp);
         dev_free(L.R_ci_c); dev_free(L.S_act_rows_c); dev_free(L.dinv_c);
+        free_blocked(L.bA); free_blocked(L.bR); free_blocked(L.bS);
         L.S_rows = L.S_n_act = 0;
         L.n = L.n_coarse = 0;
     }
     dev_free(H.cinv); dev_free(H.cinv_f);
     dev_free(H.pt); dev_free(H.pt_phi); dev_free(H.pt_f); dev_free(H.pt_phi_f);
-    H.nc = 0; H.levels = 0; H.native0 = 0; H.fused = 0;
+    H.nc = 0; H.levels = 0; H.native0 = 0; H.fused = 0; H.node_nf = 0; H.blocked = 0;
 }
 int knp_amg_reset(knp_ctx* ctx, int32_t hier, int32_t n_levels, int32_t pre, int32_t post, int32_t cheby) {
     CHECK_CTX(ctx);
@@ -2760,7 +2992,9 @@ int knp_amg_set_level(knp_ctx* ctx, int32_t hier, int32_t level, int32_t n_rows,
         KCHK(build_prolong_rows(ctx, L, n_rows, P_rp));
         if (L.P_n_act > 0) L.P_lanes = pick_lanes((double)nnzP / L.P_n_act, 1);
         L.R_lanes = pick_lanes((double)nnzR / n_coarse, 2);
+        if (H.node_nf > 0 && ctx->amg_fp32) KCHK(build_blocked(ctx, H.node_nf, n_coarse, H.node_nf, level == 0 ? 4 : H.node_nf, R_rp, R_ci, R_v, &L.bR));
     }
+    if (H.node_nf > 0 && ctx->amg_fp32 && level > 0) KCHK(build_blocked(ctx, H.node_nf, n_rows, H.node_nf, H.node_nf, A_rp, A_ci, A_v, &L.bA));
     HIPCHK(hipMalloc((void**)&L.x, (size_t)n_loc * sizeof(double)));
     HIPCHK(hipMalloc((void**)&L.b, (size_t)n_loc * sizeof(double)));
     HIPCHK(hipMemset(L.b, 0, (size_t)n_loc * sizeof(double)));
@@ -2818,6 +3052,8 @@ int knp_amg_set_level_smoothed(knp_ctx* ctx, int32_t hier, int32_t level, int32_
     L.S_rows = n_rows;
     KCHK(build_act_rows(ctx, n_rows, S_rp, &L.S_act_rows, &L.S_act_rp, &L.S_n_act));
     L.S_lanes = pick_lanes((double)nnzS / std::max(L.S_n_act > 0 ? L.S_n_act : n_rows, 1), 1);
+    const int nf = ctx->hier[hier].node_nf;
+    if (nf > 0 && ctx->amg_fp32) KCHK(build_blocked(ctx, nf, n_rows, level == 0 ? 4 : nf, nf, S_rp, S_ci, S_v, &L.bS));
     return KNP_OK;
 }
 int knp_amg_set_level_mode(knp_ctx* ctx, int32_t hier, int32_t level, int32_t distributed, int32_t repl_n) {
@@ -3133,6 +3369,29 @@ static void amg_cycle_fused(knp_ctx* ctx, KnpAmgHier& H, const double* b, double
         if (H.pt_f) launch_l0_down<float>(st, fm, ctx->pc_group, nn, ctx->d_pair_ptr, ctx->d_pair_col, H.pt_f, b, c0, L0.r);
         else launch_l0_down<double>(st, fm, ctx->pc_group, nn, ctx->d_pair_ptr, ctx->d_pair_col, H.pt, b, c0, L0.r);
     }
+    if (H.blocked) {   // node-blocked transfer and level operators (node-synchronised hierarchy): same cycle, one row per node
+        const int nf = H.node_nf;
+        for (int l = 0; l < nl - 1; ++l) {
+            KnpAmgLevel& L = H.lv[l];
+            KnpAmgLevel& C = H.lv[l + 1];
+            if (l + 1 == nl - 1) {
+                launch_brestrict(st, nf, l == 0 ? 4 : nf, L.bR, L.r, C.b, 0.0, nullptr, nullptr, nullptr);
+                if (H.cinv_f) launch_dense_matvec<float>(st, H.nc, H.cinv_f, C.b, C.x);
+                else launch_dense_matvec<double>(st, H.nc, H.cinv, C.b, C.x);
+            } else {
+                launch_brestrict(st, nf, l == 0 ? 4 : nf, L.bR, L.r, C.b, cheb_c(C), C.inv_diag, C.d, C.x);
+                if (nf == 4) launch_bresidual_t<4>(st, C.bA, C.x, C.b, C.r);
+                else launch_bresidual_t<3>(st, C.bA, C.x, C.b, C.r);
+            }
+        }
+        for (int l = nl - 2; l >= 0; --l) {
+            KnpAmgLevel& L = H.lv[l];
+            const double c = cheb_c(L);
+            if (l > 0) launch_blevel_up(st, nf, nf, L.bS, H.lv[l + 1].x, L.inv_diag, L.b, L.r, L.x, c, c, L.x);
+            else launch_blevel_up(st, nf, 4, L.bS, H.lv[1].x, L.inv_diag, b, L.r, nullptr, c, c, z);
+        }
+        return;
+    }
     // down the hierarchy
     for (int l = 0; l < nl - 1; ++l) {
         KnpAmgLevel& L = H.lv[l];
@@ -3207,6 +3466,17 @@ int knp_pc_setup(knp_ctx* ctx, int32_t kind) {
         const bool ok = fused_eligible(ctx, ctx->hier[0]) && fused_eligible(ctx, ctx->hier[1]) && ctx->hier[1].native0 == 3 && ctx->hier[0].native0 == 2 &&
                         ctx->hier[1].lv[0].S_n_act > 0 && ctx->hier[1].lv[0].S_act_rows_c && ctx->hier[1].lv[0].R_ci_c;
         ctx->hier[0].fused = ctx->hier[1].fused = ok ? 1 : 0;
+    }
+    for (int h = 0; h < KNP_MAX_HIER; ++h) {   // node-blocked operators under the fused cycle: every level must have them
+        KnpAmgHier& H = ctx->hier[h];
+        const bool off = getenv("KNP_BLOCKED") && atoi(getenv("KNP_BLOCKED")) == 0;
+        bool ok = !off && H.fused && H.node_nf > 0 && (H.native0 == 1 || H.native0 == 2) && (H.native0 == 1) == (H.node_nf == 4);
+        for (int l = 0; ok && l < H.levels - 1; ++l) {
+            const KnpAmgLevel& L = H.lv[l];
+            ok = L.bR.rp && L.bS.rp && (l == 0 || L.bA.rp) && L.bR.n_rows * H.node_nf == L.n_coarse &&
+                 L.bS.n_rows * (l == 0 ? 4 : H.node_nf) == L.n;
+        }
+        H.blocked = ok ? 1 : 0;
     }
     for (int h = 0; h < KNP_MAX_HIER; ++h) {   // level 0 in fused form inside the level-by-level cycle (distributed hierarchies)
         KnpAmgHier& H = ctx->hier[h];
@@ -3647,6 +3917,7 @@ int knp_get_stats(const knp_ctx* ctx, double* out) {
     out[KNP_ST_READBACK] = (double)ctx->n_readback;
     out[KNP_ST_FUSED] = (double)(ctx->hier[0].fused + 2 * ctx->hier[1].fused + 4 * ctx->hier[0].l0_fused + 8 * ctx->hier[1].l0_fused);
     out[KNP_ST_NORM_FALLBACK] = (double)ctx->n_norm_fallback;
+    out[KNP_ST_BLOCKED] = (double)(ctx->hier[0].blocked + 2 * ctx->hier[1].blocked);
     return KNP_OK;
 }
 

@@ -97,7 +97,8 @@ def oracle_gmres_same_algorithm(kind, N, steps, pc, rtol, solver, models="ci"):
 
     def fac(P):
         if pc == "btcc":
-            hk = rnd(amg.build_hierarchy(amg.restrict_to_fields(P, (0, 1, 2)), theta=solver.amg_theta, coarse_size=solver.amg_coarse_size), coarse=fused)
+            hk = rnd(amg.build_hierarchy(amg.restrict_to_fields(P, (0, 1, 2)), theta=solver.amg_theta, coarse_size=solver.amg_coarse_size,
+                                         node_fields=solver.ion_node_fields()), coarse=fused)
             hp = rnd(amg.build_hierarchy(amg.restrict_to_fields(P, (3,)), theta=solver.amg_theta, coarse_size=solver.amg_coarse_size))
             return K.pc_btcc(o, hk, hp, pre, post, deg, fused=fused)
         h = rnd(amg.build_hierarchy(P, theta=solver.amg_theta, coarse_size=solver.amg_coarse_size))

@@ -456,6 +456,41 @@ def test_fused_cycle_is_the_same_operator_as_the_unfused_cycle(kind, N, pc, flag
         assert np.max(np.abs(z1[f::4] - z0[f::4])) <= tol * np.max(np.abs(z0[f::4])), f
 
 
+@pytest.mark.parametrize("kind,N", [("cube", 10), ("square", 40)])
+def test_node_blocked_cycle_is_the_same_operator_as_the_scalar_cycle(kind, N, monkeypatch):
+    """Ion hierarchy built with node-synchronised aggregation (cgx_hip/amg.py ``node_fields``): the library keeps node-blocked
+    copies of R, the coarse operators and S (one column node per entry, three values behind it) and the fused cycle runs on
+    them.  Same linear operator as the scalar-row kernels on the same fp32-stored hierarchy, to summation order."""
+    from CGx.KNPEMI.KNPEMIx_solver import SolverKNPEMI
+    cfg = ci_config(N=N, steps=1, rtol=1e-9, kind=kind, pc="btcc")
+    cfg["solver"]["ksp_settings"]["amg_coarse_size"] = 100
+    p = make_problem(cfg)
+    s = SolverKNPEMI(p, solver_config=p.solver_config)
+    s.setup_solver()
+    be = s.backend
+    p.setup_preconditioner(s.use_block_Jacobi)
+    s.assemble_preconditioner()
+    assert s.hierarchies[0].node_fields == 3 and len(s.hierarchies[0].levels) >= 3
+    be.assemble_rhs()
+    be.assemble_matrix()
+    be.pc_setup(s._pc_kind)
+    st = be.stats()
+    assert st["fused"] == 3 and st["blocked"] == 1
+    rng = np.random.default_rng(5)
+    r = torch.as_tensor(rng.standard_normal(be.n_dof_owned), device=be.device)
+    z1 = torch.zeros_like(r)
+    be.pc_apply(r, z1)
+    monkeypatch.setenv("KNP_BLOCKED", "0")
+    be.pc_setup(s._pc_kind)
+    st = be.stats()
+    assert st["fused"] == 3 and st["blocked"] == 0
+    z0 = torch.zeros_like(r)
+    be.pc_apply(r, z0)
+    z0, z1 = z0.cpu().numpy(), z1.cpu().numpy()
+    for f in range(4):
+        assert np.max(np.abs(z1[f::4] - z0[f::4])) <= 1e-12 * np.max(np.abs(z0[f::4])), f
+
+
 @pytest.mark.parametrize("N,kind", [(24, "square"), (8, "cube")])
 def test_non_block_jacobi_form_of_P(N, kind, monkeypatch):
     """``use_block_Jacobi = False`` (class switch of the reference's solver, KNPEMIx_solver.py:37; form KNPEMIx_problem.py:720-722):

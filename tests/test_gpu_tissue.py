@@ -158,7 +158,8 @@ def test_membrane_dominated_surrogate_at_scale():
                        stimulus_tags=tags, stimulus_region=(0, lo * 1e-6, hi * 1e-6))
 
     def fac(P):
-        hk = amg.fp32_stored(amg.build_hierarchy(amg.restrict_to_fields(P, (0, 1, 2)), theta=s.amg_theta, coarse_size=s.amg_coarse_size), coarse=True)
+        hk = amg.fp32_stored(amg.build_hierarchy(amg.restrict_to_fields(P, (0, 1, 2)), theta=s.amg_theta, coarse_size=s.amg_coarse_size,
+                                                 node_fields=s.ion_node_fields()), coarse=True)
         hp = amg.fp32_stored(amg.build_hierarchy(amg.restrict_to_fields(P, (3,)), theta=s.amg_theta, coarse_size=s.amg_coarse_size))
         return K.pc_btcc(o, hk, hp, s.amg_pre, s.amg_post, s.amg_cheby_degree, fused=True)
     _, its = o.run(2, solver="gmres", pc=fac, rtol=1e-9)

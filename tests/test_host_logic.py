@@ -328,6 +328,39 @@ def test_device_amg_setup_reproduces_the_host_setup():
         assert np.abs(h0.coarse_inv - h1.coarse_inv).max() <= 1e-8 * np.abs(h0.coarse_inv).max()
 
 
+def test_node_synchronised_aggregation_shares_patterns_between_fields():
+    """``node_fields`` (amg.build_hierarchy): the ion fields are aggregated once, on the node graph of the first one, so
+    coarse unknowns are numbered nf*aggregate+k and every operator of the hierarchy has the same sparsity pattern in all
+    fields and no coupling between them (the ion blocks of P are uncoupled, reference KNPEMI/ProblemKNPEMI.py:560-620).
+    Host and device builders agree."""
+    import numpy as np
+    import knpemi_oracle as K
+    from cgx_hip import amg, amg_gpu
+    o = K.make_cube(8, models=K.CI_MODELS())
+    Pm = amg.restrict_to_fields(o.assemble_P(), (0, 1, 2))
+    h0 = amg.build_hierarchy(Pm, theta=0.08, coarse_size=100, node_fields=(4, (0, 1, 2)))
+    h1 = amg_gpu.build_hierarchy(Pm, theta=0.08, coarse_size=100, device="cpu", node_fields=(4, (0, 1, 2)))
+    assert h0.node_fields == 3 and h1.node_fields == 3 and len(h0.levels) >= 3
+    assert h0.describe()["rows"] == h1.describe()["rows"]
+    for li, (a, b) in enumerate(zip(h0.levels, h1.levels)):
+        assert abs(a.A - b.A).max() <= 1e-12 * abs(a.A).max()
+        if a.P is not None:
+            assert abs(a.P - b.P).max() <= 1e-12
+        stride = 4 if li == 0 else 3
+        mats = [(a.A, stride, (0, 1, 2))] + ([(a.P, 3, (0, 1, 2)), (a.S, 3, (0, 1, 2))] if a.P is not None else [])
+        for M, cstride, cfields in mats:
+            M = M.tocsr()
+            pats = []
+            for f, cf in zip((0, 1, 2), cfields):
+                rows = M[f::stride]
+                blk = rows[:, cf::cstride].tocsr()
+                blk.sort_indices()
+                assert blk.nnz == rows.nnz, "an ion row couples to another field"
+                pats.append((blk.indptr.copy(), blk.indices.copy()))
+            for pp in pats[1:]:
+                assert np.array_equal(pp[0], pats[0][0]) and np.array_equal(pp[1], pats[0][1])
+
+
 def test_recursive_coordinate_bisection_partition():
     """General meshes are cut by recursive coordinate bisection: balanced, deterministic, compact (2x2x2 blocks on a
     cube for 8 ranks -> far fewer cut edges than 8 slabs)."""
