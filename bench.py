@@ -426,7 +426,8 @@ def cpu_baseline(case, args, solver, snap):
                                                      node_fields=(4, (0, 1, 2)) if solver.amg_node_sync else None), coarse=fused)
                 built["p"] = rnd(amg.build_hierarchy(amg.restrict_to_fields(P, (3,)), theta=solver.amg_theta, coarse_size=solver.amg_coarse_size))
             else:
-                built["h"] = rnd(amg.build_hierarchy(P, theta=solver.amg_theta, coarse_size=solver.amg_coarse_size))
+                built["h"] = rnd(amg.build_hierarchy(P, theta=solver.amg_theta, coarse_size=solver.amg_coarse_size,
+                                                     node_fields=(4, (0, 1, 2, 3)) if solver.amg_node_sync else None))
         if pc == "btcc":
             return K.pc_btcc(o, wrap(built["k"]), wrap(built["p"]), pre, post, deg, fused=fused)
         h = wrap(built["h"])

@@ -189,7 +189,7 @@ class SolverKNPEMI:
             else:
                 build = host_build
             if self._pc_kind == _lib.PC_AMG:
-                self.hierarchy = build(P)
+                self.hierarchy = build(P, self.all_node_fields())
                 amg.upload(be.lib, be.ctx, be.check, self.hierarchy, self.amg_pre, self.amg_post, self.amg_cheby_degree, index=0)
                 be.check(be.lib.knp_amg_use_native_level0(be.ctx, 0, 1))   # level 0 is the library's own P
                 self.hierarchies = [self.hierarchy]
@@ -209,6 +209,10 @@ class SolverKNPEMI:
     def ion_node_fields(self):
         """``node_fields`` of the ion hierarchy (amg.build_hierarchy): the three ion blocks of P have the same graph"""
         return (4, (0, 1, 2)) if self.amg_node_sync else None
+
+    def all_node_fields(self):
+        """``node_fields`` of the all-field hierarchy (``hypre`` form): the potential follows the aggregates of the ion graph"""
+        return (4, (0, 1, 2, 3)) if self.amg_node_sync else None
 
     def _assemble_distributed_amg(self, P_loc):
         """Multi-GPU: one global smoothed-aggregation hierarchy (cgx_hip/dist_amg.py) instead of per-GPU blocks."""

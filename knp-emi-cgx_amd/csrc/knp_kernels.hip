@@ -2841,45 +2841,51 @@ static void free_blocked(KnpBlockedCsr& M) {
     M.n_rows = 0;
 }
 // Node-blocked copy of a scalar CSR whose rows come in groups of rs per row node (fields 0..nf-1 used, the others empty) and whose
-// columns are cs*node + field, when every field of a node row has the same column nodes in the same order (sorted rows).  The
-// pattern is VERIFIED here; a matrix that does not have it is left without a blocked copy (out->rp == nullptr) and the cycle
-// stays on the scalar kernels.
+// columns are cs*node + field with the field of the row (decoupled fields, sorted rows).  The column nodes of a node row are the
+// UNION over its fields, absent entries stored as zeros (identical patterns by construction for the ion fields; the potential
+// additionally couples the two sides of a membrane vertex).  The structure is VERIFIED here; a matrix that does not have it, or
+// whose union would add more than a quarter to the stored values, is left without a blocked copy (out->rp == nullptr) and the
+// cycle stays on the scalar kernels.
 static int build_blocked(knp_ctx* ctx, int nf, int n_rows_scalar, int rs, int cs, const int32_t* rp, const int32_t* ci, const double* v,
                          KnpBlockedCsr* out) {
     free_blocked(*out);
     if ((nf != 3 && nf != 4) || rs < nf || cs < nf || n_rows_scalar <= 0 || n_rows_scalar % rs != 0) return KNP_OK;
     const int nn = n_rows_scalar / rs;
     std::vector<int32_t> brp((size_t)nn + 1, 0);
+    std::vector<float4> ev;
+    std::vector<int32_t> bci;
+    ev.reserve((size_t)rp[n_rows_scalar] / nf + 16);
+    if (nf == 4) bci.reserve((size_t)rp[n_rows_scalar] / nf + 16);
     for (int i = 0; i < nn; ++i) {
         const int r0 = rs * i;
-        const int cnt = rp[r0 + 1] - rp[r0];
-        for (int k = 1; k < rs; ++k)
-            if (rp[r0 + k + 1] - rp[r0 + k] != (k < nf ? cnt : 0)) return KNP_OK;
-        brp[(size_t)i + 1] = brp[i] + cnt;
-    }
-    const int64_t nnz = brp[nn];
-    std::vector<float4> ev((size_t)nnz);
-    std::vector<int32_t> bci(nf == 4 ? (size_t)nnz : 0);
-    for (int i = 0; i < nn; ++i) {
-        const int r0 = rs * i;
-        const int cnt = brp[(size_t)i + 1] - brp[i];
-        for (int q = 0; q < cnt; ++q) {
-            const int c0 = ci[rp[r0] + q];
-            if (c0 % cs != 0) return KNP_OK;
-            const int j = c0 / cs;
+        for (int k = nf; k < rs; ++k)
+            if (rp[r0 + k + 1] != rp[r0 + k]) return KNP_OK;
+        int64_t q[4], e[4];
+        for (int k = 0; k < nf; ++k) { q[k] = rp[r0 + k]; e[k] = rp[r0 + k + 1]; }
+        for (;;) {
+            int jmin = INT32_MAX;
+            for (int k = 0; k < nf; ++k)
+                if (q[k] < e[k]) {
+                    const int c = ci[q[k]];
+                    if (c % cs != k) return KNP_OK;                                   // a field couples to another one
+                    if (q[k] > rp[r0 + k] && ci[q[k] - 1] >= c) return KNP_OK;        // row not sorted
+                    jmin = std::min(jmin, c / cs);
+                }
+            if (jmin == INT32_MAX) break;
             float val[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int k = 0; k < nf; ++k) {
-                const int64_t e = (int64_t)rp[r0 + k] + q;
-                if (ci[e] != cs * j + k) return KNP_OK;
-                val[k] = (float)v[e];
-            }
+            for (int k = 0; k < nf; ++k)
+                if (q[k] < e[k] && ci[q[k]] / cs == jmin) val[k] = (float)v[q[k]++];
             float4 t;
             t.x = val[0]; t.y = val[1]; t.z = val[2];
-            if (nf == 4) { t.w = val[3]; bci[(size_t)brp[i] + q] = j; }
-            else { int32_t jj = j; float w; memcpy(&w, &jj, 4); t.w = w; }
-            ev[(size_t)brp[i] + q] = t;
+            if (nf == 4) { t.w = val[3]; bci.push_back(jmin); }
+            else { const int32_t jj = jmin; float w; memcpy(&w, &jj, 4); t.w = w; }
+            ev.push_back(t);
         }
+        if (ev.size() > (size_t)INT32_MAX) return KNP_OK;
+        brp[(size_t)i + 1] = (int32_t)ev.size();
     }
+    const int64_t nnz = (int64_t)ev.size();
+    if ((double)nnz * nf > 1.25 * (double)rp[n_rows_scalar] + 64.0) return KNP_OK;
     KCHK(dev_upload(ctx, &out->rp, brp));
     KCHK(dev_upload(ctx, &out->ev, ev));
     if (nf == 4) KCHK(dev_upload(ctx, &out->ci, bci));

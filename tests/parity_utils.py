@@ -101,7 +101,7 @@ def oracle_gmres_same_algorithm(kind, N, steps, pc, rtol, solver, models="ci"):
                                          node_fields=solver.ion_node_fields()), coarse=fused)
             hp = rnd(amg.build_hierarchy(amg.restrict_to_fields(P, (3,)), theta=solver.amg_theta, coarse_size=solver.amg_coarse_size))
             return K.pc_btcc(o, hk, hp, pre, post, deg, fused=fused)
-        h = rnd(amg.build_hierarchy(P, theta=solver.amg_theta, coarse_size=solver.amg_coarse_size))
+        h = rnd(amg.build_hierarchy(P, theta=solver.amg_theta, coarse_size=solver.amg_coarse_size, node_fields=solver.all_node_fields()))
         return K.pc_amg_vcycle(h.levels, h.coarse_inv, pre, post, deg, fused=fused)
     _, its = o.run(steps, solver="gmres", pc=fac, rtol=rtol)
     return o, its

@@ -456,13 +456,15 @@ def test_fused_cycle_is_the_same_operator_as_the_unfused_cycle(kind, N, pc, flag
         assert np.max(np.abs(z1[f::4] - z0[f::4])) <= tol * np.max(np.abs(z0[f::4])), f
 
 
-@pytest.mark.parametrize("kind,N", [("cube", 10), ("square", 40)])
-def test_node_blocked_cycle_is_the_same_operator_as_the_scalar_cycle(kind, N, monkeypatch):
-    """Ion hierarchy built with node-synchronised aggregation (cgx_hip/amg.py ``node_fields``): the library keeps node-blocked
-    copies of R, the coarse operators and S (one column node per entry, three values behind it) and the fused cycle runs on
-    them.  Same linear operator as the scalar-row kernels on the same fp32-stored hierarchy, to summation order."""
+@pytest.mark.parametrize("kind,N,pc,nf", [("cube", 10, "btcc", 3), ("square", 40, "btcc", 3), ("square", 48, "hypre", 4), ("cube", 8, "hypre", 4)])
+def test_node_blocked_cycle_is_the_same_operator_as_the_scalar_cycle(kind, N, pc, nf, monkeypatch):
+    """Hierarchies built with node-synchronised aggregation (cgx_hip/amg.py ``node_fields``: the ion hierarchy of the
+    block-triangular form, all four fields in the ``hypre`` form): the library keeps node-blocked copies of R, the coarse
+    operators and S (one column node per entry, nf values behind it; union pattern with zeros where the potential alone
+    couples the two sides of a membrane vertex) and the fused cycle runs on them.  Same linear operator as the scalar-row
+    kernels on the same fp32-stored hierarchy, to summation order."""
     from CGx.KNPEMI.KNPEMIx_solver import SolverKNPEMI
-    cfg = ci_config(N=N, steps=1, rtol=1e-9, kind=kind, pc="btcc")
+    cfg = ci_config(N=N, steps=1, rtol=1e-9, kind=kind, pc=pc)
     cfg["solver"]["ksp_settings"]["amg_coarse_size"] = 100
     p = make_problem(cfg)
     s = SolverKNPEMI(p, solver_config=p.solver_config)
@@ -470,12 +472,13 @@ def test_node_blocked_cycle_is_the_same_operator_as_the_scalar_cycle(kind, N, mo
     be = s.backend
     p.setup_preconditioner(s.use_block_Jacobi)
     s.assemble_preconditioner()
-    assert s.hierarchies[0].node_fields == 3 and len(s.hierarchies[0].levels) >= 3
+    assert s.hierarchies[0].node_fields == nf and len(s.hierarchies[0].levels) >= 3
     be.assemble_rhs()
     be.assemble_matrix()
     be.pc_setup(s._pc_kind)
     st = be.stats()
-    assert st["fused"] == 3 and st["blocked"] == 1
+    fused = 3 if pc == "btcc" else 1
+    assert st["fused"] == fused and st["blocked"] == 1
     rng = np.random.default_rng(5)
     r = torch.as_tensor(rng.standard_normal(be.n_dof_owned), device=be.device)
     z1 = torch.zeros_like(r)
@@ -483,7 +486,7 @@ def test_node_blocked_cycle_is_the_same_operator_as_the_scalar_cycle(kind, N, mo
     monkeypatch.setenv("KNP_BLOCKED", "0")
     be.pc_setup(s._pc_kind)
     st = be.stats()
-    assert st["fused"] == 3 and st["blocked"] == 0
+    assert st["fused"] == fused and st["blocked"] == 0
     z0 = torch.zeros_like(r)
     be.pc_apply(r, z0)
     z0, z1 = z0.cpu().numpy(), z1.cpu().numpy()
