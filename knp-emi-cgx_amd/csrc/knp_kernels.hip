@@ -1119,6 +1119,12 @@ __device__ __forceinline__ void breduce(double s[4]) {
         if (NF == 4) s[3] += __shfl_xor(s[3], o, L);
     }
 }
+// After the butterfly every lane of the group holds all NF sums: lane k (< NF) finishes field k, so the epilogue's loads and
+// stores are one instruction over NF lanes instead of NF instructions on lane 0 (groups of 2 lanes: lane 0 does all of them).
+template <int NF>
+__device__ __forceinline__ double bpick(const double s[4], int k) {
+    return k == 0 ? s[0] : k == 1 ? s[1] : (NF == 4 && k == 3) ? s[3] : s[2];
+}
 // b_c = R r  [; d_c = x_c = c Dinv_c b_c when dinv is given]          rows: coarse nodes (NF unknowns each)
 template <int L, int NF, int XS>
 __global__ void __launch_bounds__(NT)
@@ -1127,18 +1133,29 @@ k_brestrict(int n_rows, const int32_t* __restrict__ rp, const float4* __restrict
             double* __restrict__ d, double* __restrict__ xo) {
     const int row = (blockIdx.x * NT + threadIdx.x) / L;
     const int lane = threadIdx.x & (L - 1);
+    constexpr int KL = L >= NF ? 1 : NF;   // fields finished per epilogue lane
+    const bool fin = row < n_rows && (L >= NF ? lane < NF : lane == 0);
     double s[4] = {0.0, 0.0, 0.0, 0.0};
-    if (row < n_rows) brow_dot<L, NF, XS>(rp[row], rp[row + 1], lane, ev, ci, x, s);
-    breduce<L, NF>(s);
-    if (lane == 0 && row < n_rows) {
-        const size_t i = (size_t)NF * row;
+    double di[KL];
+    if (row < n_rows) {
+        if (fin && dinv) {
 #pragma unroll
-        for (int k = 0; k < NF; ++k) {
-            y[i + k] = s[k];
+            for (int k = 0; k < KL; ++k) di[k] = dinv[(size_t)NF * row + (L >= NF ? lane : k)];
+        }
+        brow_dot<L, NF, XS>(rp[row], rp[row + 1], lane, ev, ci, x, s);
+    }
+    breduce<L, NF>(s);
+    if (fin) {
+#pragma unroll
+        for (int k = 0; k < KL; ++k) {
+            const int f = L >= NF ? lane : k;
+            const size_t i = (size_t)NF * row + f;
+            const double sk = bpick<NF>(s, f);
+            y[i] = sk;
             if (dinv) {
-                const double t = c * dinv[i + k] * s[k];
-                d[i + k] = t;
-                xo[i + k] = t;
+                const double t = c * di[k] * sk;
+                d[i] = t;
+                xo[i] = t;
             }
         }
     }
@@ -1150,19 +1167,24 @@ k_bresidual(int n_rows, const int32_t* __restrict__ rp, const float4* __restrict
             const double* __restrict__ x, const double* __restrict__ b, double* __restrict__ y) {
     const int row = (blockIdx.x * NT + threadIdx.x) / L;
     const int lane = threadIdx.x & (L - 1);
+    constexpr int KL = L >= NF ? 1 : NF;
+    const bool fin = row < n_rows && (L >= NF ? lane < NF : lane == 0);
     double s[4] = {0.0, 0.0, 0.0, 0.0};
-    double bv[4] = {0.0, 0.0, 0.0, 0.0};
+    double bv[KL];
     if (row < n_rows) {
-        if (lane == 0) {
+        if (fin) {
 #pragma unroll
-            for (int k = 0; k < NF; ++k) bv[k] = b[(size_t)NF * row + k];
+            for (int k = 0; k < KL; ++k) bv[k] = b[(size_t)NF * row + (L >= NF ? lane : k)];
         }
         brow_dot<L, NF, NF>(rp[row], rp[row + 1], lane, ev, ci, x, s);
     }
     breduce<L, NF>(s);
-    if (lane == 0 && row < n_rows) {
+    if (fin) {
 #pragma unroll
-        for (int k = 0; k < NF; ++k) y[(size_t)NF * row + k] = bv[k] - s[k];
+        for (int k = 0; k < KL; ++k) {
+            const int f = L >= NF ? lane : k;
+            y[(size_t)NF * row + f] = bv[k] - bpick<NF>(s, f);
+        }
     }
 }
 // z = x0 + c2 Dinv r + S xc for the NF unknowns of every node row; x0 = xin when given, else c Dinv b.  RS = unknowns per ROW node
@@ -1174,25 +1196,28 @@ k_blevel_up(int n_rows, const int32_t* __restrict__ rp, const float4* __restrict
             const double* xin, double c, double c2, double* z) {
     const int row = (blockIdx.x * NT + threadIdx.x) / L;
     const int lane = threadIdx.x & (L - 1);
+    constexpr int KL = L >= NF ? 1 : NF;
+    const bool fin = row < n_rows && (L >= NF ? lane < NF : lane == 0);
     double s[4] = {0.0, 0.0, 0.0, 0.0};
-    double di[4], ri[4], x0[4];
+    double base[KL];
     if (row < n_rows) {
-        if (lane == 0) {   // the epilogue's operands travel together with the gathers
-            const size_t i = (size_t)RS * row;
+        if (fin) {   // the epilogue's operands travel together with the gathers
 #pragma unroll
-            for (int k = 0; k < NF; ++k) {
-                di[k] = dinv[i + k];
-                ri[k] = r[i + k];
-                x0[k] = xin ? xin[i + k] : c * di[k] * b[i + k];
+            for (int k = 0; k < KL; ++k) {
+                const size_t i = (size_t)RS * row + (L >= NF ? lane : k);
+                const double di = dinv[i];
+                base[k] = (xin ? xin[i] : c * di * b[i]) + c2 * di * r[i];
             }
         }
         brow_dot<L, NF, NF>(rp[row], rp[row + 1], lane, ev, ci, xc, s);
     }
     breduce<L, NF>(s);
-    if (lane == 0 && row < n_rows) {
-        const size_t i = (size_t)RS * row;
+    if (fin) {
 #pragma unroll
-        for (int k = 0; k < NF; ++k) z[i + k] = x0[k] + c2 * di[k] * ri[k] + s[k];
+        for (int k = 0; k < KL; ++k) {
+            const int f = L >= NF ? lane : k;
+            z[(size_t)RS * row + f] = base[k] + bpick<NF>(s, f);
+        }
     }
 }
 #define KNP_BL_SWITCH(LANES, CALL) \
