@@ -189,6 +189,10 @@ struct knp_ctx {
     double* d_contrib_k = nullptr;
     int32_t *d_node_cell_ptr = nullptr, *d_node_cell = nullptr;
     uint8_t* d_contrib_slot = nullptr;
+    int64_t* d_tc_meta = nullptr;   // transposed contribution lists (k_assemble_nodes_tr): per node base | trips << 48 | self index << 56
+    double* d_tc_k = nullptr;
+    uint8_t* d_tc_slot = nullptr;
+    int64_t n_tc = 0;
     int asm_stage = 0;    // cells per node the staged assembly reserves LDS for (0: gather per contribution)
     int32_t* d_fv = nullptr;
     double* d_fmeas = nullptr;

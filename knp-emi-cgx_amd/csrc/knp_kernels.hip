@@ -289,11 +289,113 @@ k_assemble_nodes_staged(int n_nodes, DevParams P, int cmax, const int32_t* __res
     if (live && self_p >= 0) emit(self_p, -T0, -T1, -T2);
 }
 
+// The staged kernel with the node's contributions stored TRANSPOSED: contribution t of the node's off-diagonal pair j sits at
+// base(node) + t * (number of off-diagonal pairs) + j, lists padded with zeros to the longest one of the node (an even number).
+// Consecutive lanes then stream consecutive K_ab(T) values and slots (one 8-byte and one 1-byte load per lane and trip, each a
+// contiguous ~112-byte piece per node) where the pair-major lists put ~40 bytes between neighbouring lanes and made every load
+// walk ~20 cache lines per wave.  `meta[node]` = base | trips << 48 | (index of the self pair among the node's pairs, 255: none) << 56.
+template <bool PRECOND, bool TD_ONLY, int G>
+__global__ void __launch_bounds__(NT)
+k_assemble_nodes_tr(int n_nodes, DevParams P, int cmax, const int32_t* __restrict__ pair_ptr, const uint8_t* __restrict__ node_side,
+                    const double* __restrict__ pair_M, const double* __restrict__ pair_K, const int64_t* __restrict__ meta,
+                    const uint8_t* __restrict__ tslot, const double* __restrict__ tk, const int32_t* __restrict__ node_cell_ptr,
+                    const int32_t* __restrict__ node_cell, const double* __restrict__ cbar, double* __restrict__ at, double* __restrict__ ac) {
+    extern __shared__ double lds[];   // [NT / G][cmax][3]
+    const int node_raw = (blockIdx.x * NT + threadIdx.x) / G;
+    const int lane = threadIdx.x & (G - 1);
+    const bool live = node_raw < n_nodes;
+    const int node = live ? node_raw : n_nodes - 1;
+    double* mine = lds + (size_t)(threadIdx.x / G) * cmax * 3;
+    const int64_t mt = meta[node];
+    const int p0 = pair_ptr[node];
+    const int deg = pair_ptr[node + 1] - p0;
+    {
+        const int c0 = node_cell_ptr[node], c1 = node_cell_ptr[node + 1];
+        for (int i = c0 + lane; i < c1; i += G) {
+            const int cell = node_cell[i];
+            const double2 c01 = *reinterpret_cast<const double2*>(cbar + (size_t)4 * cell);
+            const double c2 = cbar[(size_t)4 * cell + 2];
+            double* d = mine + 3 * (i - c0);
+            d[0] = c01.x; d[1] = c01.y; d[2] = c2;
+        }
+    }
+    __syncthreads();
+    const int64_t base = mt & 0xffffffffffffLL;
+    const int trips = (int)((mt >> 48) & 0xff);
+    const int selfq = (int)((mt >> 56) & 0xff);
+    const int dod = deg - (selfq < 255 ? 1 : 0);
+    const int side = node_side[node];
+    const double D0 = side ? P.De[0] : P.Di[0], D1 = side ? P.De[1] : P.Di[1], D2 = side ? P.De[2] : P.Di[2];
+    const double f0 = P.dt * D0 * P.z[0] / P.psi, f1 = P.dt * D1 * P.z[1] / P.psi, f2 = P.dt * D2 * P.z[2] / P.psi;
+    auto emit = [&](int p, double S0, double S1, double S2) {
+        const double phiphi = f0 * P.z[0] * S0 + f1 * P.z[1] * S1 + f2 * P.z[2] * S2;
+        if (!PRECOND) {
+            *reinterpret_cast<double2*>(at + 4 * (size_t)p) = make_double2(f0 * S0, f1 * S1);
+            *reinterpret_cast<double2*>(at + 4 * (size_t)p + 2) = make_double2(f2 * S2, phiphi);
+            if (!TD_ONLY) {
+                const double M = pair_M[p], K = pair_K[p];
+                *reinterpret_cast<double2*>(ac + 6 * (size_t)p) = make_double2(M + P.dt * D0 * K, M + P.dt * D1 * K);
+                *reinterpret_cast<double2*>(ac + 6 * (size_t)p + 2) = make_double2(M + P.dt * D2 * K, P.dt * P.z[0] * D0 * K);
+                *reinterpret_cast<double2*>(ac + 6 * (size_t)p + 4) = make_double2(P.dt * P.z[1] * D1 * K, P.dt * P.z[2] * D2 * K);
+            }
+        } else {
+            const double M = pair_M[p], K = pair_K[p];
+            *reinterpret_cast<double2*>(at + 4 * (size_t)p) = make_double2(M + P.dt * D0 * K, M + P.dt * D1 * K);
+            *reinterpret_cast<double2*>(at + 4 * (size_t)p + 2) = make_double2(M + P.dt * D2 * K, phiphi);
+        }
+    };
+    double T0 = 0.0, T1 = 0.0, T2 = 0.0;
+    for (int q = lane; q < deg; q += G) {
+        if (q == selfq) continue;
+        const int j = q - (q > selfq ? 1 : 0);
+        const double* __restrict__ kk = tk + base + j;
+        const uint8_t* __restrict__ ss = tslot + base + j;
+        double S0 = 0.0, S1 = 0.0, S2 = 0.0;
+        // two contributions in flight per lane (four or six, or more resident waves, measured no faster on MI355X);
+        // trips is even; padded entries are K = 0 on slot 0
+        for (int t = 0; t < trips; t += 2) {
+            const double k = kk[(size_t)t * dod], k2 = kk[(size_t)(t + 1) * dod];
+            const double* u = mine + 3 * (int)ss[(size_t)t * dod];
+            const double* w = mine + 3 * (int)ss[(size_t)(t + 1) * dod];
+            S0 += k * u[0];
+            S1 += k * u[1];
+            S2 += k * u[2];
+            S0 += k2 * w[0];
+            S1 += k2 * w[1];
+            S2 += k2 * w[2];
+        }
+        if (live) emit(p0 + q, S0, S1, S2);
+        T0 += S0; T1 += S1; T2 += S2;
+    }
+#pragma unroll
+    for (int o = G >> 1; o > 0; o >>= 1) {
+        T0 += __shfl_xor(T0, o, G);
+        T1 += __shfl_xor(T1, o, G);
+        T2 += __shfl_xor(T2, o, G);
+    }
+    if (live && selfq < 255 && (selfq & (G - 1)) == lane) emit(p0 + selfq, -T0, -T1, -T2);
+}
+
 template <bool PRECOND, bool TD_ONLY>
 static void launch_assemble_nodes(knp_ctx* ctx, const DevParams& P, double* at, double* ac) {
     const KnpHostGraph& g = ctx->g;
     const int n = g.n_nodes_owned;
     if (n <= 0) return;
+    if (ctx->asm_stage > 0 && ctx->d_tc_meta) {   // staged + transposed contribution lists (default)
+        const int cmax = ctx->asm_stage;
+#define KNP_ASMT(GG) hipLaunchKernelGGL((k_assemble_nodes_tr<PRECOND, TD_ONLY, GG>), dim3(nblocks((int64_t)n * GG)), dim3(NT),                        \
+                                        (size_t)(NT / GG) * cmax * 3 * sizeof(double), ctx->stream, n, P, cmax, ctx->d_pair_ptr, ctx->d_node_side,     \
+                                        ctx->d_pair_M, ctx->d_pair_K, ctx->d_tc_meta, ctx->d_tc_slot, ctx->d_tc_k, ctx->d_node_cell_ptr,              \
+                                        ctx->d_node_cell, ctx->d_cbar, at, ac)
+        switch (ctx->asm_group) {
+            case 4: KNP_ASMT(4); break;
+            case 8: KNP_ASMT(8); break;
+            case 16: KNP_ASMT(16); break;
+            default: KNP_ASMT(32); break;
+        }
+#undef KNP_ASMT
+        return;
+    }
     if (ctx->asm_stage > 0) {   // cell means staged in LDS (default)
         const int cmax = ctx->asm_stage;
 #define KNP_ASMS(GG) hipLaunchKernelGGL((k_assemble_nodes_staged<PRECOND, TD_ONLY, GG>), dim3(nblocks((int64_t)n * GG)), dim3(NT),                    \
@@ -2090,6 +2192,53 @@ extern "C" {
 
 const char* knp_last_error(const knp_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
 
+// Transposed contribution lists of k_assemble_nodes_tr (layout described there).  Skipped (the pair-major lists stay in use) when
+// the zero padding would add more than half to the stored contributions -- meshes whose edges have very uneven cell counts.
+static int build_transposed_contribs(knp_ctx* ctx) {
+    const KnpHostGraph& g = ctx->g;
+    const int no = g.n_nodes_owned;
+    std::vector<int64_t> meta((size_t)std::max(no, 1), 0);
+    int64_t total = 0;
+    for (int n = 0; n < no; ++n) {
+        const int p0 = g.pair_ptr[n], p1 = g.pair_ptr[n + 1];
+        int selfq = 255, tmax = 0;
+        for (int p = p0; p < p1; ++p) {
+            if (g.pair_col[p] == n) { if (p - p0 < 255) selfq = p - p0; else return KNP_OK; }
+            tmax = std::max(tmax, g.contrib_ptr[p + 1] - g.contrib_ptr[p]);
+        }
+        tmax = (tmax + 1) & ~1;
+        if (tmax > 254) return KNP_OK;
+        const int dod = (p1 - p0) - (selfq < 255 ? 1 : 0);
+        meta[n] = total | ((int64_t)tmax << 48) | ((int64_t)selfq << 56);
+        total += (int64_t)tmax * dod;
+    }
+    if (total >= (1LL << 47) || (double)total > 1.5 * (double)g.contrib_k.size() + 1024.0) return KNP_OK;
+    std::vector<double> tk((size_t)std::max<int64_t>(total, 1), 0.0);
+    std::vector<uint8_t> ts((size_t)std::max<int64_t>(total, 1), 0);
+#pragma omp parallel for schedule(static)
+    for (int n = 0; n < no; ++n) {
+        const int p0 = g.pair_ptr[n], p1 = g.pair_ptr[n + 1];
+        const int64_t base = meta[n] & 0xffffffffffffLL;
+        const int selfq = (int)((meta[n] >> 56) & 0xff);
+        const int dod = (p1 - p0) - (selfq < 255 ? 1 : 0);
+        for (int p = p0; p < p1; ++p) {
+            const int q = p - p0;
+            if (q == selfq) continue;
+            const int j = q - (q > selfq ? 1 : 0);
+            int t = 0;
+            for (int c = g.contrib_ptr[p]; c < g.contrib_ptr[p + 1]; ++c, ++t) {
+                tk[(size_t)(base + (int64_t)t * dod + j)] = g.contrib_k[c];
+                ts[(size_t)(base + (int64_t)t * dod + j)] = g.contrib_slot[c];
+            }
+        }
+    }
+    KCHK(dev_upload(ctx, &ctx->d_tc_meta, meta));
+    KCHK(dev_upload(ctx, &ctx->d_tc_k, tk));
+    KCHK(dev_upload(ctx, &ctx->d_tc_slot, ts));
+    ctx->n_tc = total;
+    return KNP_OK;
+}
+
 int knp_create(knp_ctx** out, const knp_mesh_desc* mesh) {
     if (!out) return KNP_E_ARG;
     *out = nullptr;
@@ -2139,6 +2288,8 @@ int knp_create(knp_ctx** out, const knp_mesh_desc* mesh) {
             KCHK(dev_upload(ctx, &ctx->d_node_cell_ptr, g.node_cell_ptr));
             KCHK(dev_upload(ctx, &ctx->d_node_cell, g.node_cell));
             KCHK(dev_upload(ctx, &ctx->d_contrib_slot, g.contrib_slot));
+            const char* et = getenv("KNP_ASM_TRANSPOSED");
+            if (!(et && atoi(et) == 0)) KCHK(build_transposed_contribs(ctx));
         } else {
             KCHK(dev_upload(ctx, &ctx->d_contrib_cell, g.contrib_cell));
         }
@@ -2254,6 +2405,7 @@ int knp_destroy(knp_ctx* ctx) {
     dev_free(ctx->d_pair_M); dev_free(ctx->d_pair_K);
     dev_free(ctx->d_contrib_ptr); dev_free(ctx->d_contrib_cell); dev_free(ctx->d_contrib_k);
     dev_free(ctx->d_node_cell_ptr); dev_free(ctx->d_node_cell); dev_free(ctx->d_contrib_slot);
+    dev_free(ctx->d_tc_meta); dev_free(ctx->d_tc_k); dev_free(ctx->d_tc_slot);
     dev_free(ctx->d_fv); dev_free(ctx->d_fmeas); dev_free(ctx->d_gamma_prog); dev_free(ctx->d_qp); dev_free(ctx->d_qw);
     dev_free(ctx->d_gv_vertex); dev_free(ctx->d_gv_node_i); dev_free(ctx->d_gv_node_e); dev_free(ctx->d_node_gv);
     dev_free(ctx->d_gptr); dev_free(ctx->d_gcol); dev_free(ctx->d_grow); dev_free(ctx->d_gq_i); dev_free(ctx->d_gq_e);
