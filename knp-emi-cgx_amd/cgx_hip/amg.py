@@ -203,6 +203,17 @@ def build_hierarchy(P: sp.csr_matrix, theta: float = 0.08, max_levels: int = 12,
             nn = n // stride
             A0 = A[fields[0]::stride][:, fields[0]::stride].tocsr()
             Sn = strength_graph(A0, theta * 0.25 ** len(levels))
+            if not levels:
+                # the other fields must be able to follow the first one's aggregates: a node that has strong neighbours there
+                # but none in field f (a row of f dominated by its diagonal, e.g. the membrane mass of the potential in the
+                # non-dimensional MMS setting) is smoothed well by Jacobi alone and spoils the coarse operators when it is
+                # aggregated with its neighbours; so does a field whose diagonal is not positive where the first one's is (the
+                # potential block of P in the MMS setting is indefinite: minus sign on its membrane mass)
+                deg0 = np.diff(Sn.indptr)
+                for f in fields[1:]:
+                    Sf = strength_graph(A[f::stride][:, f::stride].tocsr(), theta)
+                    if np.any((np.diff(Sf.indptr) == 0) & (deg0 > 0)) or np.any((diag[f::stride] <= 0.0) & (diag[fields[0]::stride] > 0.0)):
+                        return build_hierarchy(P, theta, max_levels, coarse_size, smooth_prolongator, agg_distance, None)   # unsynchronised
             act_n = active[fields[0]::stride]
             ian = np.nonzero(act_n)[0]
             if act_n.all():

@@ -204,6 +204,14 @@ def build_hierarchy(P, theta: float = 0.08, max_levels: int = 12, coarse_size: i
             m0 = (r_ % stride == f0) & (c_ % stride == f0)
             A0 = _from_coo(torch.div(r_[m0], stride, rounding_mode="floor"), torch.div(c_[m0], stride, rounding_mode="floor"), v_[m0], (nn, nn))
             skey_n = _strength(A0, th)
+            if not levels:      # same compatibility rule as the host builder (amg.build_hierarchy)
+                deg0 = torch.bincount(torch.div(skey_n, nn, rounding_mode="floor"), minlength=nn)
+                for f in fields[1:]:
+                    mf = (r_ % stride == f) & (c_ % stride == f)
+                    Af = _from_coo(torch.div(r_[mf], stride, rounding_mode="floor"), torch.div(c_[mf], stride, rounding_mode="floor"), v_[mf], (nn, nn))
+                    degf = torch.bincount(torch.div(_strength(Af, th), nn, rounding_mode="floor"), minlength=nn)
+                    if bool(((degf == 0) & (deg0 > 0)).any()) or bool(((diag[f::stride] <= 0) & (diag[f0::stride] > 0)).any()):
+                        return build_hierarchy(P, theta, max_levels, coarse_size, agg_distance, device, None)
             act_n = active[f0::stride]
             ian = torch.nonzero(act_n).squeeze(1)
             n_act_n = int(ian.numel())

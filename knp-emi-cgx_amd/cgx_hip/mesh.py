@@ -7,9 +7,10 @@ Replaces (host side, setup only):
   * the '+' = intracellular ordering of interior-facet integration entities,
     src/CGx/utils/mixed_dim_problem.py:705-729.
 
-XDMF/HDF5 reading is out of scope (no h5py here): a config whose ``cell_tag_file`` is named
-``square<N>.xdmf`` / ``cube<N>.xdmf`` / ``tissue<dim>d_<N>_<m>[_g<gap>|_w<width>].xdmf`` is generated natively; ``*.npz`` files with arrays
-``coords, cells, cell_tags, facets, facet_tags`` are loaded as they are.
+Mesh input (``load_mesh``): an existing ``.xdmf`` file (+ its ``.h5``) is read by cgx_hip/xdmf.py (DOLFINx and meshio layouts,
+decoded without an HDF5 library); ``*.npz`` files with arrays ``coords, cells, cell_tags, facets, facet_tags`` are loaded as
+they are; a ``cell_tag_file`` that does not exist and is named ``square<N>.xdmf`` / ``cube<N>.xdmf`` /
+``tissue<dim>d_<N>_<m>[_g<gap>|_w<width>].xdmf`` is generated natively (what generate_square_mesh.py would have written).
 """
 from __future__ import annotations
 
@@ -247,6 +248,11 @@ def load_mesh(mesh_file, facet_file, conversion_factor=1.0):
         d = np.load(mesh_file, allow_pickle=False)
         ft = (d["facets"], d["facet_tags"]) if "facets" in d.files else None
         return d["coords"] * conversion_factor, d["cells"].astype(np.int32), d["cell_tags"].astype(np.int32), ft, mesh_file
+    if mesh_file.endswith(".xdmf") and os.path.exists(mesh_file):
+        from . import xdmf
+        ff = facet_file if (facet_file and os.path.exists(facet_file)) else mesh_file
+        coords, cells, tags, ft = xdmf.read_mesh_and_tags(mesh_file, ff)
+        return coords * conversion_factor, cells, tags, ft, f"{mesh_file} (XDMF)"
     m = _TISSUE.search(base)
     if m:
         dim, N, nb, gap = int(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(4) or 1)
@@ -263,5 +269,5 @@ def load_mesh(mesh_file, facet_file, conversion_factor=1.0):
         coords, cells = create_unit_square(N) if kind == "square" else create_unit_cube(N)
         tags = mark_subdomains_box(coords, cells)
         return coords * conversion_factor, cells, tags, None, f"generated {kind}{N}"
-    raise RuntimeError(f"Cannot read mesh '{mesh_file}': only 'square<N>'/'cube<N>' synthetic meshes and .npz "
-                       "meshes are supported by the MI355X-native path (XDMF/HDF5 input is out of scope).")
+    raise RuntimeError(f"Cannot read mesh '{mesh_file}': the file does not exist and its name is not one of the generated "
+                       "meshes ('square<N>', 'cube<N>', 'tissue<dim>d_<N>_<m>...'); .xdmf (+ .h5) and .npz meshes are read from disk.")

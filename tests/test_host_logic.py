@@ -361,6 +361,25 @@ def test_node_synchronised_aggregation_shares_patterns_between_fields():
                 assert np.array_equal(pp[0], pats[0][0]) and np.array_equal(pp[1], pats[0][1])
 
 
+def test_node_synchronised_aggregation_declines_an_indefinite_potential_block():
+    """P of the MMS problem on the 32x32 square (tests/golden/mms_P_square32.npz, assembled by the HIP path and dumped with
+    tools/dump_mms.py): non-dimensional constants make the membrane mass of the potential block (minus sign in the
+    reference's form, KNPEMIx_problem.py:657-744) larger than its stiffness, the diagonal turns negative on membrane nodes.
+    Following the ion aggregates there gives a V-cycle with eigenvalues of both signs (GMRES then stalls: 2000 iterations
+    on the GPU); both builders must fall back to the unsynchronised aggregation for such a matrix."""
+    import os
+    import numpy as np
+    import scipy.sparse as sp
+    from cgx_hip import amg, amg_gpu
+    P = sp.load_npz(os.path.join(os.path.dirname(__file__), "golden", "mms_P_square32.npz")).tocsr()
+    assert P.diagonal()[3::4].min() < 0 < P.diagonal()[0::4].min()
+    h0 = amg.build_hierarchy(P)
+    for h in (amg.build_hierarchy(P, node_fields=(4, (0, 1, 2, 3))), amg_gpu.build_hierarchy(P, node_fields=(4, (0, 1, 2, 3)), device="cpu")):
+        assert h.node_fields == 0 and h.describe()["rows"] == h0.describe()["rows"]
+    # the ion fields alone are fine
+    assert amg.build_hierarchy(amg.restrict_to_fields(P, (0, 1, 2)), node_fields=(4, (0, 1, 2))).node_fields == 3
+
+
 def test_recursive_coordinate_bisection_partition():
     """General meshes are cut by recursive coordinate bisection: balanced, deterministic, compact (2x2x2 blocks on a
     cube for 8 ranks -> far fewer cut edges than 8 slabs)."""
