@@ -238,7 +238,7 @@ def timed_run(case, args, world, dist, torch, steps, warmup, snapshot_at=None, a
             ni, ne = solver.potential_norms()
             snap = {"step": st.i, "phi_i": ni, "phi_e": ne, "phi_m": case["problem"].phi_m_prev.numpy().copy()}
     be.profile_reset()
-    be.profile_enable(profile_mask)
+    be.profile_enable(int(os.environ.get("KNP_BENCH_PROFILE_MASK", profile_mask)))      # (developer knob: 0 = no events at all)
     reps, its_all, reasons = [], [], []
     total = 0.0
     while True:

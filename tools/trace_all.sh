@@ -1,0 +1,12 @@
+#!/bin/bash
+# Developer tool (GPU box, repo root): kernel stats + last-step timeline of the three bench workloads into gpurun_out/<tag>/
+TAG=${1:-trace}; R=${GRAFT_REPO_ROOT:-$PWD}; mkdir -p $R/gpurun_out/$TAG
+cd /tmp && export TMPDIR=/tmp
+for w in square512 cube64 cube136; do
+  D=$R/gpurun_out/$TAG/prof_$w
+  rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python $R/bench.py --workload $w --large none --no-cpu-baseline --no-repeat --steps 6 --warmup 2 --set amg_setup=host > $R/gpurun_out/$TAG/prof_$w.log 2>&1
+  T=$(find $D -name "*kernel_trace.csv" | head -1); S=$(find $D -name "*kernel_stats.csv" | head -1)
+  python $R/tools/trace_step.py $T > $R/gpurun_out/$TAG/timeline_$w.txt
+  cp $S $R/gpurun_out/$TAG/kernel_stats_$w.csv
+  rm -rf $D
+done
