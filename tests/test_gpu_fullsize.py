@@ -147,6 +147,30 @@ def test_second_assembly_matches_oracle_entrywise(N, kind, monkeypatch):
     assert np.array_equal(A3.indices, A2.indices) and np.array_equal(A3.data, A2.data)
 
 
+@pytest.mark.parametrize("N,kind", [(16, "square"), (6, "cube")])
+def test_assembly_variants_write_the_same_bits(N, kind, monkeypatch):
+    """The volume-assembly kernels sum a pair's contributions in the same order: transposed per-node contribution lists (the
+    default) and pair-major lists, both with the cell means staged in LDS, write the same bits (the zero padding of the
+    transposed lists adds +0.0); the plain gather without LDS differs in the last bit of a few entries (the compiler
+    contracts its multiply-adds differently)."""
+    from test_gpu_parity import _setup
+
+    def build():
+        p, be, o = _setup(N, kind)
+        be.assemble_matrix()
+        be.assemble_precond()
+        return be.csr(), be.precond_csr()
+    A1, P1 = build()
+    monkeypatch.setenv("KNP_ASM_TRANSPOSED", "0")
+    A2, P2 = build()
+    monkeypatch.setenv("KNP_ASM_STAGE", "0")
+    A3, P3 = build()
+    assert np.array_equal(A2.indices, A1.indices) and np.array_equal(A2.data, A1.data)
+    assert np.array_equal(P2.indices, P1.indices) and np.array_equal(P2.data, P1.data)
+    assert np.array_equal(A3.indices, A1.indices) and np.abs(A3.data - A1.data).max() <= 1e-15 * np.abs(A1.data).max()
+    assert np.array_equal(P3.indices, P1.indices) and np.abs(P3.data - P1.data).max() <= 1e-15 * np.abs(P1.data).max()
+
+
 @pytest.mark.parametrize("kind,N", [("cube", 8), ("square", 24)])
 def test_side_stream_prenorm_is_bitwise_the_inline_value(kind, N, monkeypatch):
     """||B b|| computed on the side stream next to the matrix assembly (knp_gmres_prepare, btcc: reads the Schur diagonal
