@@ -155,6 +155,10 @@ class RunOutput:
             solver.gamma_point_values = np.zeros((n, len(p.gamma_points)))
         if solver.save_cpoints:
             os.makedirs(os.path.join(self.prefix, "checkpoints"), exist_ok=True)
+        self.xdmf = None
+        if getattr(solver, "save_xdmfs", False):
+            os.makedirs(self.prefix, exist_ok=True)
+            self.init_xdmf_savefile()
 
     # ---- KNPEMIx_solver.py:551-610
     def _trace_point(self):
@@ -179,6 +183,103 @@ class RunOutput:
             s.gamma_point_values[i] = self.gamma_eval([p.phi_m_prev])[0]
         if s.save_cpoints and (i % s.save_interval == 0):
             self.checkpoint(i)
+        if self.xdmf is not None and i > 0 and (i % s.save_interval == 0):       # reference :471
+            self.save_xdmf()
+
+    # ---- KNPEMIx_solver.py:766-797, 824-831: subdomains.xdmf (mesh + cell tags) and solution.xdmf (time series of the 2(N+1)
+    # nodal functions), heavy data in .h5 files next to them (cgx_hip/hdf5_write.py); one pair of files per rank
+    def _xdmf_names(self, stem):
+        p = self.p
+        sfx = f"_rank{p.comm.rank}" if p.comm.size > 1 else ""
+        return os.path.join(self.prefix, stem + sfx + ".xdmf"), os.path.join(self.prefix, stem + sfx + ".h5")
+
+    def _mesh_items(self, h5name, n_cells, n_pts, dim):
+        ttype = "Triangle" if dim == 2 else "Tetrahedron"
+        return [f'      <Topology TopologyType="{ttype}" NumberOfElements="{n_cells}" NodesPerElement="{dim + 1}">',
+                f'        <DataItem Dimensions="{n_cells} {dim + 1}" NumberType="Int" Precision="8" Format="HDF">{h5name}:/Mesh/mesh/topology</DataItem>',
+                f'      </Topology>',
+                f'      <Geometry GeometryType="{"XY" if dim == 2 else "XYZ"}">',
+                f'        <DataItem Dimensions="{n_pts} {dim}" NumberType="Float" Precision="8" Format="HDF">{h5name}:/Mesh/mesh/geometry</DataItem>',
+                f'      </Geometry>']
+
+    def _tag_grid(self, h5name, n_cells, n_pts, dim):
+        return ['    <Grid Name="ct" GridType="Uniform">'] + self._mesh_items(h5name, n_cells, n_pts, dim)[:3] + [
+            f'      <Geometry GeometryType="{"XY" if dim == 2 else "XYZ"}">',
+            f'        <DataItem Dimensions="{n_pts} {dim}" NumberType="Float" Precision="8" Format="HDF">{h5name}:/Mesh/mesh/geometry</DataItem>',
+            f'      </Geometry>',
+            f'      <Attribute Name="ct" AttributeType="Scalar" Center="Cell">',
+            f'        <DataItem Dimensions="{n_cells} 1" NumberType="Int" Precision="4" Format="HDF">{h5name}:/MeshTags/ct/Values</DataItem>',
+            f'      </Attribute>',
+            f'    </Grid>']
+
+    @staticmethod
+    def _xdmf_text(body):
+        return "\n".join(['<?xml version="1.0"?>', '<!DOCTYPE Xdmf SYSTEM "Xdmf.dtd" []>', '<Xdmf Version="3.0">', '  <Domain>'] + body + ['  </Domain>', '</Xdmf>', ''])
+
+    def init_xdmf_savefile(self):
+        from .hdf5_write import Hdf5Writer
+        p = self.p
+        lm = p.local_mesh
+        coords = np.asarray(lm.coords, dtype=np.float64)
+        cells = np.asarray(lm.cells, dtype=np.int64)
+        tags = np.asarray(lm.cell_tags, dtype=np.int32).reshape(-1, 1)
+        dim = cells.shape[1] - 1
+        nc, npt = len(cells), len(coords)
+        for stem in ("subdomains", "solution"):
+            xname, hname = self._xdmf_names(stem)
+            w = Hdf5Writer(hname)
+            w.write("/Mesh/mesh/geometry", coords)
+            w.write("/Mesh/mesh/topology", cells)
+            w.write("/MeshTags/ct/topology", cells)
+            w.write("/MeshTags/ct/Values", tags)
+            base = os.path.basename(hname)
+            head = ['    <Grid Name="mesh" GridType="Uniform">'] + self._mesh_items(base, nc, npt, dim) + ['    </Grid>'] + self._tag_grid(base, nc, npt, dim)
+            if stem == "subdomains":
+                w.close()
+                with open(xname, "w") as f:
+                    f.write(self._xdmf_text(head))
+            else:
+                self.xdmf = {"writer": w, "xname": xname, "h5": base, "head": head, "steps": [], "dims": (nc, npt, dim)}
+        self.save_xdmf()                               # initial state, reference :787-790
+
+    def save_xdmf(self):
+        """the 2(N+1) solution functions at the current time (reference :792-797), appended to solution.h5"""
+        if self.xdmf is None:
+            return
+        p = self.p
+        X = self.xdmf
+        k = len(X["steps"])
+        names = []
+        for idx in range(p.num_variables):
+            for side in (0, 1):
+                f = p.wh[side][idx]
+                X["writer"].write(f"/Function/{f.name}/{k}", np.asarray(f.numpy(), dtype=np.float64).reshape(-1, 1))
+                names.append(f.name)
+        X["steps"].append((float(p.t.value), names))
+        self._write_solution_xml()
+
+    def _write_solution_xml(self):
+        X = self.xdmf
+        nc, npt, dim = X["dims"]
+        body = list(X["head"]) + ['    <Grid Name="solution" GridType="Collection" CollectionType="Temporal">']
+        for k, (t, names) in enumerate(X["steps"]):
+            body += [f'      <Grid Name="step_{k}" GridType="Uniform">', f'        <Time Value="{t!r}" />']
+            body += ["  " + ln for ln in self._mesh_items(X["h5"], nc, npt, dim)]
+            for nm in names:
+                body += [f'        <Attribute Name="{nm}" AttributeType="Scalar" Center="Node">',
+                         f'          <DataItem Dimensions="{npt} 1" NumberType="Float" Precision="8" Format="HDF">{X["h5"]}:/Function/{nm}/{k}</DataItem>',
+                         f'        </Attribute>']
+            body += ['      </Grid>']
+        body += ['    </Grid>']
+        with open(X["xname"], "w") as f:
+            f.write(self._xdmf_text(body))
+
+    def close_xdmf(self):
+        if self.xdmf is not None:
+            self.xdmf["writer"].close()                # the .h5 file becomes readable here (metadata + superblock)
+            self._write_solution_xml()
+            self.p.print("\nXDMF output saved in ", self.prefix)
+            self.xdmf = None
 
     def checkpoint(self, i):
         """nodal values of the 2(N+1) solution functions (+ phi_m and the gating variables) of this rank's owned vertices"""

@@ -99,9 +99,6 @@ class SolverKNPEMI:
         self.save_mat = out.get("save_mat", False)
         if "save_interval" in out:
             self.save_interval = out["save_interval"]
-        if self.save_xdmfs:
-            raise NotImplementedError("XDMF/HDF5 output needs an HDF5 library (none in this environment); use save_cpoints "
-                                      "(.npz checkpoints of the nodal fields) and save_dat (.npy traces) instead.")
         self.out_file_prefix = problem.output_dir
         self.direct_solver = bool(solver_config["direct"])
         self.view_input = solver_config.get("view_ksp", False)
@@ -289,7 +286,7 @@ class SolverKNPEMI:
         self.assembly_time = []
         # traces, probe points, checkpoints (reference :96-99: init_png_savefile / init_checkpoint_file / init_data)
         from .output import RunOutput
-        self.output = RunOutput(self) if (self.save_pngs or self.save_dat or self.save_cpoints or p.point_evaluation) else None
+        self.output = RunOutput(self) if (self.save_pngs or self.save_dat or self.save_cpoints or self.save_xdmfs or p.point_evaluation) else None
         if self.output is not None:
             self.output.record(0)
 
@@ -405,6 +402,8 @@ class SolverKNPEMI:
                     self.output.figures()
                 if self.save_dat:
                     self.export_data()
+                if self.save_xdmfs and self.output is not None:
+                    self.output.close_xdmf()           # reference :482-484
 
     def potential_norms(self):
         """L2 norms of phi_i over Omega_i and phi_e over Omega_e (reference main.py:70-84)."""

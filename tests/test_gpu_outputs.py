@@ -92,3 +92,40 @@ def test_point_evaluation_traces_and_checkpoints_match_oracle(tmp_path):
     vi = o.lay.node_i >= 0
     assert np.allclose(ck["Na_i"][vi], snaps[1][0][0][0][vi], rtol=1e-7)
     assert np.allclose(ck["phi_m"][gv], snaps[1][1][gv], rtol=1e-6)
+
+
+def test_save_xdmf_writes_mesh_tags_and_time_series(tmp_path):
+    """``save_xdmf: True`` (reference KNPEMIx_solver.py:766-797): subdomains.xdmf and solution.xdmf + .h5, written without an
+    HDF5 library; read back through the package's XDMF/HDF5 reader: the mesh and tags are the run's, the last time level holds
+    the solver's final fields, the first one the initial state."""
+    from CGx.KNPEMI import main as cli
+    from cgx_hip import hdf5_min, xdmf
+    import xml.etree.ElementTree as ET
+    N, steps = 8, 4
+    out_dir = str(tmp_path) + os.sep
+    cfg = ci_config(N=N, steps=steps, rtol=1e-10)
+    cfg["quiet"] = True
+    cfg["output_dir"] = out_dir
+    cfg["solver"]["output"].update({"save_xdmf": True, "save_interval": 2})
+    yml = tmp_path / "square_xdmf.yaml"
+    yml.write_text(yaml.safe_dump(cfg))
+    solver = cli.main(["--config", str(yml), "--view", "0"])
+    p = solver.problem
+    lm = p.local_mesh
+    # the tag file is a mesh file the reader (and the reference's read_mesh / read_meshtags) accepts
+    coords, cells, ct, _ = xdmf.read_mesh_and_tags(out_dir + "subdomains.xdmf", out_dir + "subdomains.xdmf")
+    assert np.array_equal(coords, lm.coords) and np.array_equal(cells, lm.cells) and np.array_equal(ct, lm.cell_tags)
+    # time series: steps 0, 2, 4
+    root = ET.parse(out_dir + "solution.xdmf").getroot()
+    times = [float(t.get("Value")) for t in root.iter("Time")]
+    assert np.allclose(times, [0.0, 2 * cfg["dt"], 4 * cfg["dt"]], rtol=1e-12, atol=0)
+    names = [a.get("Name") for a in root.iter("Attribute") if a.get("Center") == "Node"]
+    assert set(names) == {"Na_i", "Na_e", "K_i", "K_e", "Cl_i", "Cl_e", "phi_i", "phi_e"} and len(names) == 3 * 8
+    h = hdf5_min.Hdf5File(out_dir + "solution.h5")
+    assert h.keys("/Function/phi_i") == ["0", "1", "2"]
+    for side in range(2):
+        for idx in range(4):
+            f = p.wh[side][idx]
+            assert np.array_equal(h.read(f"/Function/{f.name}/2").ravel(), f.numpy())
+    vi = p.local_mesh.cells[p.cell_side == 0]
+    assert np.allclose(h.read("/Function/Na_i/0").ravel()[np.unique(vi)], 12.0) and np.allclose(h.read("/Function/K_e/0").ravel()[np.unique(p.local_mesh.cells[p.cell_side == 1])], 4.0)
