@@ -1186,28 +1186,32 @@ __device__ __forceinline__ void bload_x(const double* __restrict__ x, int j, dou
         xv[3] = NF == 4 ? p[3] : 0.0;
     }
 }
-// two predicated entries in flight per lane (each: 16 B entry + 24/32 B gather)
+// four predicated entries in flight per lane (each: 16 B entry + 24/32 B gather)
 template <int L, int NF, int XS>
 __device__ __forceinline__ void brow_dot(int k0, int e, int lane, const float4* __restrict__ ev, const int32_t* __restrict__ ci,
                                          const double* __restrict__ x, double s[4]) {
-    for (int q = k0 + lane; q < e; q += 2 * L) {
-        const int q2 = min(q + L, e - 1);
-        const bool h2 = q + L < e;
-        const float4 a = ev[q], b = ev[q2];
-        const int ja = NF == 3 ? __float_as_int(a.w) : ci[q];
-        const int jb = NF == 3 ? __float_as_int(b.w) : ci[q2];
-        double xa[4], xb[4];
-        bload_x<NF, XS>(x, ja, xa);
-        bload_x<NF, XS>(x, jb, xb);
-        s[0] += (double)a.x * xa[0];
-        s[1] += (double)a.y * xa[1];
-        s[2] += (double)a.z * xa[2];
-        if (NF == 4) s[3] += (double)a.w * xa[3];
-        if (h2) {
-            s[0] += (double)b.x * xb[0];
-            s[1] += (double)b.y * xb[1];
-            s[2] += (double)b.z * xb[2];
-            if (NF == 4) s[3] += (double)b.w * xb[3];
+    for (int q = k0 + lane; q < e; q += 4 * L) {
+        int qq[4];
+        float4 a[4];
+        int j[4];
+        double xv[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            qq[i] = min(q + i * L, e - 1);
+            a[i] = ev[qq[i]];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) j[i] = NF == 3 ? __float_as_int(a[i].w) : ci[qq[i]];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bload_x<NF, XS>(x, j[i], xv[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i == 0 || q + i * L < e) {
+                s[0] += (double)a[i].x * xv[i][0];
+                s[1] += (double)a[i].y * xv[i][1];
+                s[2] += (double)a[i].z * xv[i][2];
+                if (NF == 4) s[3] += (double)a[i].w * xv[i][3];
+            }
         }
     }
 }
@@ -3024,7 +3028,7 @@ static void free_blocked(KnpBlockedCsr& M) {
 // whose union would add more than a quarter to the stored values, is left without a blocked copy (out->rp == nullptr) and the
 // cycle stays on the scalar kernels.
 static int build_blocked(knp_ctx* ctx, int nf, int n_rows_scalar, int rs, int cs, const int32_t* rp, const int32_t* ci, const double* v,
-                         KnpBlockedCsr* out) {
+                         KnpBlockedCsr* out, bool restrictor = false) {
     free_blocked(*out);
     if ((nf != 3 && nf != 4) || rs < nf || cs < nf || n_rows_scalar <= 0 || n_rows_scalar % rs != 0) return KNP_OK;
     const int nn = n_rows_scalar / rs;
@@ -3068,8 +3072,10 @@ static int build_blocked(knp_ctx* ctx, int nf, int n_rows_scalar, int rs, int cs
     if (nf == 4) KCHK(dev_upload(ctx, &out->ci, bci));
     out->n_rows = nn;
     static const double scale = getenv("KNP_LANE_SCALE_B") ? atof(getenv("KNP_LANE_SCALE_B")) : 1.0;
-    const double avg = scale * (double)nnz / nn;   // two entries in flight per lane
-    out->lanes = avg <= 6.0 ? 2 : avg <= 12.0 ? 4 : avg <= 28.0 ? 8 : avg <= 64.0 ? 16 : 32;
+    // four entries in flight per lane; measured on MI355X (cube 136^3 / 512^2): about 4 entries per lane for S and the level
+    // operators, 2 for the restrictors (long rows whose gathers of the fine residual miss the caches more often)
+    const double avg = scale * (restrictor ? 2.0 : 1.0) * (double)nnz / nn;
+    out->lanes = avg <= 10.0 ? 2 : avg <= 20.0 ? 4 : avg <= 44.0 ? 8 : avg <= 100.0 ? 16 : 32;
     return KNP_OK;
 }
 int knp_amg_set_node_fields(knp_ctx* ctx, int32_t hier, int32_t nf) {
@@ -3175,7 +3181,7 @@ int knp_amg_set_level(knp_ctx* ctx, int32_t hier, int32_t level, int32_t n_rows,
         KCHK(build_prolong_rows(ctx, L, n_rows, P_rp));
         if (L.P_n_act > 0) L.P_lanes = pick_lanes((double)nnzP / L.P_n_act, 1);
         L.R_lanes = pick_lanes((double)nnzR / n_coarse, 2);
-        if (H.node_nf > 0 && ctx->amg_fp32) KCHK(build_blocked(ctx, H.node_nf, n_coarse, H.node_nf, level == 0 ? 4 : H.node_nf, R_rp, R_ci, R_v, &L.bR));
+        if (H.node_nf > 0 && ctx->amg_fp32) KCHK(build_blocked(ctx, H.node_nf, n_coarse, H.node_nf, level == 0 ? 4 : H.node_nf, R_rp, R_ci, R_v, &L.bR, true));
     }
     if (H.node_nf > 0 && ctx->amg_fp32 && level > 0) KCHK(build_blocked(ctx, H.node_nf, n_rows, H.node_nf, H.node_nf, A_rp, A_ci, A_v, &L.bA));
     HIPCHK(hipMalloc((void**)&L.x, (size_t)n_loc * sizeof(double)));
