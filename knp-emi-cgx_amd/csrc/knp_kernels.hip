@@ -1039,38 +1039,37 @@ k_l0_down(int n_nodes, const int32_t* __restrict__ pair_ptr, const int32_t* __re
                 if (q + 2 * G < deg) s3 += vc * xc;
                 if (q + 3 * G < deg) s3 += vd * xd;
             }
-        } else {         // two predicated trips in flight per lane: 2 x (4 B index + 16/32 B values + 32 B gather)
-            for (int q = lane; q < deg; q += 2 * G) {
-                const int q2 = min(q + G, deg - 1);
-                const bool h2 = q + G < deg;
-                const int nb = pair_col[p0 + q], nb2 = pair_col[p0 + q2];
-                double a0, a1, a2, a3, e0, e1, e2, e3;
-                if (sizeof(VT) == 4) {
-                    const float4 pq = *reinterpret_cast<const float4*>(pt + 4 * (size_t)(p0 + q));
-                    const float4 pr = *reinterpret_cast<const float4*>(pt + 4 * (size_t)(p0 + q2));
-                    a0 = pq.x; a1 = pq.y; a2 = pq.z; a3 = pq.w;
-                    e0 = pr.x; e1 = pr.y; e2 = pr.z; e3 = pr.w;
-                } else {
-                    const double2 u = *reinterpret_cast<const double2*>(pt + 4 * (size_t)(p0 + q));
-                    const double2 w = *reinterpret_cast<const double2*>(pt + 4 * (size_t)(p0 + q) + 2);
-                    const double2 u2 = *reinterpret_cast<const double2*>(pt + 4 * (size_t)(p0 + q2));
-                    const double2 w2 = *reinterpret_cast<const double2*>(pt + 4 * (size_t)(p0 + q2) + 2);
-                    a0 = u.x; a1 = u.y; a2 = w.x; a3 = w.y;
-                    e0 = u2.x; e1 = u2.y; e2 = w2.x; e3 = w2.y;
+        } else {         // four predicated trips in flight per lane: 4 x (4 B index + 16/32 B values + 32 B gather)
+            for (int q = lane; q < deg; q += 4 * G) {
+                int nbv[4];
+                double av[4][4];
+                double2 xa[4], xb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int qi = min(q + i * G, deg - 1);
+                    nbv[i] = pair_col[p0 + qi];
+                    if (sizeof(VT) == 4) {
+                        const float4 pq = *reinterpret_cast<const float4*>(pt + 4 * (size_t)(p0 + qi));
+                        av[i][0] = pq.x; av[i][1] = pq.y; av[i][2] = pq.z; av[i][3] = pq.w;
+                    } else {
+                        const double2 u = *reinterpret_cast<const double2*>(pt + 4 * (size_t)(p0 + qi));
+                        const double2 w = *reinterpret_cast<const double2*>(pt + 4 * (size_t)(p0 + qi) + 2);
+                        av[i][0] = u.x; av[i][1] = u.y; av[i][2] = w.x; av[i][3] = w.y;
+                    }
                 }
-                const double2 xa = *reinterpret_cast<const double2*>(b + 4 * (size_t)nb);
-                const double2 xb = *reinterpret_cast<const double2*>(b + 4 * (size_t)nb + 2);
-                const double2 ya = *reinterpret_cast<const double2*>(b + 4 * (size_t)nb2);
-                const double2 yb = *reinterpret_cast<const double2*>(b + 4 * (size_t)nb2 + 2);
-                s0 += a0 * xa.x;
-                s1 += a1 * xa.y;
-                s2 += a2 * xb.x;
-                if (FM == 0) s3 += a3 * xb.y;
-                if (h2) {
-                    s0 += e0 * ya.x;
-                    s1 += e1 * ya.y;
-                    s2 += e2 * yb.x;
-                    if (FM == 0) s3 += e3 * yb.y;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    xa[i] = *reinterpret_cast<const double2*>(b + 4 * (size_t)nbv[i]);
+                    xb[i] = *reinterpret_cast<const double2*>(b + 4 * (size_t)nbv[i] + 2);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i == 0 || q + i * G < deg) {
+                        s0 += av[i][0] * xa[i].x;
+                        s1 += av[i][1] * xa[i].y;
+                        s2 += av[i][2] * xb[i].x;
+                        if (FM == 0) s3 += av[i][3] * xb[i].y;
+                    }
                 }
             }
         }
@@ -3463,8 +3462,8 @@ static double* amg_vcycle(knp_ctx* ctx, KnpAmgHier& H, int l, const double* b, d
             if (H.pt_phi_f) launch_l0_down<float>(st, 3, Gp, nn, ctx->d_pair_ptr, ctx->d_pair_col, H.pt_phi_f, b, c0, L.r);
             else launch_l0_down<double>(st, 3, Gp, nn, ctx->d_pair_ptr, ctx->d_pair_col, H.pt_phi, b, c0, L.r);
         } else {
-            if (H.pt_f) launch_l0_down<float>(st, fm, ctx->pc_group, nn, ctx->d_pair_ptr, ctx->d_pair_col, H.pt_f, b, c0, L.r);
-            else launch_l0_down<double>(st, fm, ctx->pc_group, nn, ctx->d_pair_ptr, ctx->d_pair_col, H.pt, b, c0, L.r);
+            if (H.pt_f) launch_l0_down<float>(st, fm, std::max(2, ctx->pc_group / 2), nn, ctx->d_pair_ptr, ctx->d_pair_col, H.pt_f, b, c0, L.r);
+            else launch_l0_down<double>(st, fm, std::max(2, ctx->pc_group / 2), nn, ctx->d_pair_ptr, ctx->d_pair_col, H.pt, b, c0, L.r);
         }
     } else {
     for (int sw = 0; sw < H.pre; ++sw) { amg_smooth(ctx, H, l, b, &cur, bufA, bufB, zero, zero && first_done); zero = false; }
@@ -3555,8 +3554,8 @@ static void amg_cycle_fused(knp_ctx* ctx, KnpAmgHier& H, const double* b, double
         if (H.pt_phi_f) launch_l0_down<float>(st, 2, Gp, nn, ctx->d_pair_ptr, ctx->d_pair_col, H.pt_phi_f, b, c0, L0.r);
         else launch_l0_down<double>(st, 2, Gp, nn, ctx->d_pair_ptr, ctx->d_pair_col, H.pt_phi, b, c0, L0.r);
     } else {
-        if (H.pt_f) launch_l0_down<float>(st, fm, ctx->pc_group, nn, ctx->d_pair_ptr, ctx->d_pair_col, H.pt_f, b, c0, L0.r);
-        else launch_l0_down<double>(st, fm, ctx->pc_group, nn, ctx->d_pair_ptr, ctx->d_pair_col, H.pt, b, c0, L0.r);
+        if (H.pt_f) launch_l0_down<float>(st, fm, std::max(2, ctx->pc_group / 2), nn, ctx->d_pair_ptr, ctx->d_pair_col, H.pt_f, b, c0, L0.r);
+        else launch_l0_down<double>(st, fm, std::max(2, ctx->pc_group / 2), nn, ctx->d_pair_ptr, ctx->d_pair_col, H.pt, b, c0, L0.r);
     }
     if (H.blocked) {   // node-blocked transfer and level operators (node-synchronised hierarchy): same cycle, one row per node
         const int nf = H.node_nf;
