@@ -428,10 +428,13 @@ class SolverKNPEMI:
            "preconditioned-residual norm, one reduction per iteration")
         pr(f"  tolerances: relative={self._rtol:g}, absolute=1e-50, divergence=1e5, maximum iterations={self.ksp_max_it}")
         pr("  initial guess nonzero:", bool(self.nonzero_init_guess or self.direct_solver))
-        pr(f"PC Object: type {self.pc_type} -> native kind {self._pc_kind}", "(fused V(1,1) cycle)" if be.stats()["fused"] else "")
+        st = be.stats()
+        pr(f"PC Object: type {self.pc_type} -> native kind {self._pc_kind}", "(fused V(1,1) cycle)" if st["fused"] else "")
         for k, h in enumerate(getattr(self, "hierarchies", []) or []):
             if hasattr(h, "describe"):
-                pr(f"  hierarchy {k}:", h.describe())
+                nf = getattr(h, "node_fields", 0)
+                pr(f"  hierarchy {k}:", h.describe(),
+                   (f"node-synchronised aggregation, {nf} fields per node" + (", node-blocked operators" if (st["blocked"] >> k) & 1 else "")) if nf else "")
         pr(f"  linear system: {be.n_dof_global} unknowns, {be.nnz_global} stored entries, membrane programs: {be.lib.knp_jit_status(be.ctx).decode()}")
 
     # ---- reference :504-548
