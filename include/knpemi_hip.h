@@ -305,7 +305,8 @@ enum { KNP_ST_BNORM = 0 /* ||B b|| of the last solve */, KNP_ST_ALLREDUCE = 1 /*
        KNP_ST_FUSED = 4 /* bit h set: hierarchy h runs the fused V(1,1) cycle; bit 2+h: its level 0 runs fused inside the
                            level-by-level cycle (distributed hierarchies) */,
        KNP_ST_NORM_FALLBACK = 5 /* GMRES iterations whose norm needed a second reduction (cancellation guard) */,
-       KNP_ST_BLOCKED = 6 /* bit h set: the fused cycle of hierarchy h runs on node-blocked operators */, KNP_ST_COUNT = 8 };
+       KNP_ST_BLOCKED = 6 /* bit h set: the fused cycle of hierarchy h runs on node-blocked operators */,
+       KNP_ST_FUSED_LEVELS = 7 /* levels >= 1 that run in fused form inside the level-by-level cycle, all hierarchies */, KNP_ST_COUNT = 8 };
 int knp_get_stats(const knp_ctx* ctx, double* out /* host [KNP_ST_COUNT] */);
 
 #ifdef __cplusplus

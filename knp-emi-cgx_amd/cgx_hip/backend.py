@@ -534,7 +534,7 @@ class Backend:
         out = (C.c_double * 8)()
         self.check(self.lib.knp_get_stats(self.ctx, out))
         return {"bnorm": out[0], "allreduces": int(out[1]), "halos": int(out[2]), "readbacks": int(out[3]), "fused": int(out[4]),
-                "norm_fallbacks": int(out[5]), "blocked": int(out[6])}
+                "norm_fallbacks": int(out[5]), "blocked": int(out[6]), "fused_levels": int(out[7])}
 
     def profile_get(self):
         names = ["spmv", "orthogonalisation", "pc", "assembly", "other"]

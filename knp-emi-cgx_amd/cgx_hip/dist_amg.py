@@ -262,8 +262,7 @@ def build_distributed_hierarchy(comm, P_loc: sp.csr_matrix, halo0: LevelHalo, ow
             L.replicated = True
             L.n_coarse_own, L.n_coarse_loc = int(nagg), nagg_glob
             L.repl_n, L.repl_offset = nagg_glob, int(offs[rank])
-            if len(levels) == 0:
-                L.S = _post_smoothed(X, A, dinv, lam, L.P, L.P_loc)
+            L.S = _post_smoothed(X, A, dinv, lam, L.P, L.P_loc)
             levels.append(L)
             mine_blk = [Ac_glob.indptr.astype(np.int64), Ac_glob.indices.astype(np.int64), Ac_glob.data]
             got = exchange_arrays(comm, {r: mine_blk for r in range(size) if r != rank})
@@ -294,8 +293,7 @@ def build_distributed_hierarchy(comm, P_loc: sp.csr_matrix, halo0: LevelHalo, ow
         L.P_loc = relabel(Pm_loc, n_loc)                  # + rows of the ghost nodes
         L.R = L.P.T.tocsr()                               # n_c_loc x n_own (ghost rows -> reverse halo to their owners)
         L.n_coarse_own, L.n_coarse_loc = int(nagg), n_c_loc
-        if len(levels) == 0:
-            L.S = _post_smoothed(X, A, dinv, lam, L.P, L.P_loc)
+        L.S = _post_smoothed(X, A, dinv, lam, L.P, L.P_loc)
         levels.append(L)
         A = relabel(Ac_glob, int(nagg))
         A.sort_indices()
@@ -423,6 +421,9 @@ def upload(lib, ctx, check, levels, tail, pre=1, post=1, cheby_degree=2, index=0
             Rrp, Rci, Rv = arrs(lv.R)
             check(lib.knp_amg_set_level(ctx, index, l, n, n, ip(rp), ip(ci), fp(va), fp(dinv), float(lv.lambda_max), lv.P.shape[1],
                                         ip(Prp), ip(Pci), fp(Pv), ip(Rrp), ip(Rci), fp(Rv)))
+            if getattr(lv, "S", None) is not None:      # the tail levels run in fused form too (library: lfused)
+                Srp, Sci, Sv = arrs(lv.S)
+                check(lib.knp_amg_set_level_smoothed(ctx, index, l, n, ip(Srp), ip(Sci), fp(Sv)))
         else:
             check(lib.knp_amg_set_level(ctx, index, l, n, n, ip(rp), ip(ci), fp(va), fp(dinv), float(lv.lambda_max), 0,
                                         None, None, None, None, None, None))

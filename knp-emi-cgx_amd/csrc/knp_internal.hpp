@@ -145,6 +145,12 @@ struct KnpAmgLevel {
     int32_t *R_ci_c = nullptr, *S_act_rows_c = nullptr;
     double* dinv_c = nullptr;
     KnpBlockedCsr bA, bR, bS;   // node-blocked copies (hierarchies with node_nf > 0, fp32 storage): level operator, restrictor, S
+    // levels >= 1 in fused form inside the level-by-level cycle (distributed hierarchies and their replicated tails):
+    // At = c A Dinv on the pattern of A (ghost columns scaled with the ghost inverse diagonal), knp_pc_setup builds it
+    int64_t A_nnz = 0;
+    int lfused = 0;
+    double* At_v = nullptr;
+    float* At_vf = nullptr;
 };
 
 #define KNP_MAX_HIER 2

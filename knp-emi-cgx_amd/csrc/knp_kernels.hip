@@ -1368,6 +1368,13 @@ static void launch_blevel_up(hipStream_t st, int nf, int rs, const KnpBlockedCsr
 }
 
 // setup helpers of the fused cycle
+//   At = c A Dinv on the pattern of a CSR level operator (levels >= 1 in fused form, see amg_vcycle)
+template <typename VI, typename VO>
+__global__ void __launch_bounds__(NT)
+k_build_at(int64_t nnz, const int32_t* __restrict__ ci, const VI* __restrict__ a, const double* __restrict__ dinv, double c, VO* __restrict__ out) {
+    for (int64_t k = (int64_t)blockIdx.x * NT + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * NT)
+        out[k] = (VO)(c * (double)a[k] * dinv[ci[k]]);
+}
 //   Pt = P Dinv (pair-major, 4 fields per pair) and its compact potential part
 template <typename VT>
 __global__ void __launch_bounds__(NT)
@@ -3095,6 +3102,7 @@ static void free_hier(KnpAmgHier& H) {
         dev_free(L.S_rp); dev_free(L.S_ci); dev_free(L.S_v); dev_free(L.S_vf); dev_free(L.S_act_rows); dev_free(L.S_act_rp);
         dev_free(L.R_ci_c); dev_free(L.S_act_rows_c); dev_free(L.dinv_c);
         free_blocked(L.bA); free_blocked(L.bR); free_blocked(L.bS);
+        dev_free(L.At_v); dev_free(L.At_vf); L.lfused = 0; L.A_nnz = 0;
         L.S_rows = L.S_n_act = 0;
         L.n = L.n_coarse = 0;
     }
@@ -3145,7 +3153,7 @@ int knp_amg_set_level(knp_ctx* ctx, int32_t hier, int32_t level, int32_t n_rows,
     const int n_loc = std::max(n_cols_halo, n_rows);
     for (int64_t k = 0; k < nnzA; ++k)
         if (A_ci[k] < 0 || A_ci[k] >= n_loc) { ctx->err = "AMG level matrix column out of range"; return KNP_E_ARG; }
-    L.n = n_rows; L.n_loc = n_loc; L.n_coarse = n_coarse; L.lambda_max = lambda_max;
+    L.n = n_rows; L.n_loc = n_loc; L.n_coarse = n_coarse; L.lambda_max = lambda_max; L.A_nnz = nnzA;
     KCHK(dev_upload_raw(ctx, &L.A_rp, A_rp, (size_t)n_rows + 1));
     KCHK(dev_upload_raw(ctx, &L.A_ci, A_ci, (size_t)nnzA));
     if (ctx->amg_fp32) {   // one copy only: fp32 when the preconditioner is stored in mixed precision
@@ -3451,8 +3459,13 @@ static double* amg_vcycle(knp_ctx* ctx, KnpAmgHier& H, int l, const double* b, d
     // with P Dinv (after the halo of the INPUT: x0 = c Dinv b is local, its ghost values follow from the ghost b), and below
     // prolongation + post-smoothing as one gather with S; the levels in between keep their exchanges.
     const bool f0 = (l == 0) && H.l0_fused;
+    const bool fl = (l > 0) && L.lfused;     // the same form on a CSR level: r = b - (c A Dinv) b after the halo of b; S up-leg below
     bool zero = true;
-    if (f0) {
+    if (fl) {
+        if (L.dist && level_comm_on(ctx)) level_exchange(ctx, hidx, l, 0, const_cast<double*>(b));
+        if (L.At_vf) launch_spmv_t<1, 0, float>(st, L.A_lanes, L.n, L.A_rp, L.A_ci, L.At_vf, b, b, L.r);
+        else launch_spmv_t<1, 0, double>(st, L.A_lanes, L.n, L.A_rp, L.A_ci, L.At_v, b, b, L.r);
+    } else if (f0) {
         const double c0 = 1.0 / (0.5 * (1.1 + 0.1) * L.lambda_max);
         if (L.dist && level_comm_on(ctx)) level_exchange(ctx, hidx, 0, 0, const_cast<double*>(b));
         const int nn = ctx->g.n_nodes_owned;
@@ -3482,7 +3495,7 @@ static double* amg_vcycle(knp_ctx* ctx, KnpAmgHier& H, int l, const double* b, d
     // after this kernel (no reverse halo / all-reduce to follow)
     const bool c_last = (l + 1 == H.levels - 1);
     const bool c_smooths_first = c_last ? (H.nc == 0 && H.pre + H.post > 0) : (H.pre > 0);
-    const bool fuse_first = c_smooths_first && L.repl_n == 0 && !C.dist;
+    const bool fuse_first = c_smooths_first && L.repl_n == 0 && !C.dist && !(!c_last && C.lfused);
     if (fuse_first) {
         const int cflips = amg_flips(H, c_last);
         double* c_cur = (cflips & 1) ? C.r2 : C.x;          // where the coarse level's ping-pong starts (see below)
@@ -3498,7 +3511,7 @@ static double* amg_vcycle(knp_ctx* ctx, KnpAmgHier& H, int l, const double* b, d
     }
     double* xc = amg_vcycle(ctx, H, l + 1, C.b, nullptr, fuse_first);
     if (C.dist && level_comm_on(ctx) && L.repl_n == 0) level_exchange(ctx, hidx, l + 1, 0, xc);
-    if (f0) {   // x = c Dinv b + c Dinv r + S x_c, straight into the caller's vector
+    if (f0 || fl) {   // x = c Dinv b + c Dinv r + S x_c, straight into the caller's vector
         const double c0 = 1.0 / (0.5 * (1.1 + 0.1) * L.lambda_max);
         const int n_act = L.S_n_act > 0 ? L.S_n_act : L.S_rows;
         const int32_t* rp = L.S_n_act > 0 ? L.S_act_rp : L.S_rp;
@@ -3632,6 +3645,31 @@ static int check_hier(knp_ctx* ctx, int h) {
     return KNP_OK;
 }
 
+// At = c A Dinv of level l (>= 1): the columns of ghost unknowns are scaled with the ghost inverse diagonal, fetched with one
+// forward halo of the level (collective: every rank builds the same levels in the same order inside knp_pc_setup)
+static int build_level_scaled(knp_ctx* ctx, int hidx, int l) {
+    KnpAmgLevel& L = ctx->hier[hidx].lv[l];
+    const double c = 1.0 / (0.5 * (1.1 + 0.1) * L.lambda_max);
+    double* dloc = nullptr;
+    HIPCHK(hipMalloc((void**)&dloc, (size_t)std::max(L.n_loc, 1) * sizeof(double)));
+    HIPCHK(hipMemsetAsync(dloc, 0, (size_t)std::max(L.n_loc, 1) * sizeof(double), ctx->stream));
+    HIPCHK(hipMemcpyAsync(dloc, L.inv_diag, (size_t)L.n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    if (L.dist && level_comm_on(ctx)) level_exchange(ctx, hidx, l, 0, dloc);
+    const int nblk = (int)std::min<int64_t>(nblocks(L.A_nnz), 8192);
+    if (L.A_vf) {
+        HIPCHK(hipMalloc((void**)&L.At_vf, (size_t)L.A_nnz * sizeof(float)));
+        hipLaunchKernelGGL((k_build_at<float, float>), dim3(nblk), dim3(NT), 0, ctx->stream, L.A_nnz, L.A_ci, L.A_vf, dloc, c, L.At_vf);
+    } else {
+        HIPCHK(hipMalloc((void**)&L.At_v, (size_t)L.A_nnz * sizeof(double)));
+        hipLaunchKernelGGL((k_build_at<double, double>), dim3(nblk), dim3(NT), 0, ctx->stream, L.A_nnz, L.A_ci, L.A_v, dloc, c, L.At_v);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(dloc);
+    if (ctx->comm_rc != KNP_OK) { const int rc = ctx->comm_rc; ctx->comm_rc = KNP_OK; return rc; }
+    return KNP_OK;
+}
+
 int knp_pc_setup(knp_ctx* ctx, int32_t kind) {
     CHECK_CTX(ctx);
     side_discard(ctx);
@@ -3673,6 +3711,18 @@ int knp_pc_setup(knp_ctx* ctx, int32_t kind) {
         const bool have_pt = H.native0 == 3 ? (H.pt_phi || H.pt_phi_f) : (H.pt || H.pt_f);
         H.l0_fused = (!off && !H.fused && H.native0 > 0 && H.levels >= 2 && H.cheby == 1 && H.pre == 1 && H.post == 1 && L0.S_rp &&
                       L0.S_rows == L0.n && have_pt) ? 1 : 0;
+        // the levels below it likewise (distributed levels and the replicated tail): At = c A Dinv for the down-leg, S for the up-leg
+        const bool used = (kind == KNP_PC_AMG && h == 0) || ((kind == KNP_PC_AMG_BT || kind == KNP_PC_AMG_LT) && h < 2);
+        for (int l = 1; l < H.levels - 1; ++l) {
+            KnpAmgLevel& L = H.lv[l];
+            dev_free(L.At_v); dev_free(L.At_vf);
+            L.lfused = 0;
+            const bool lvl_off = getenv("KNP_FUSED_LEVELS") && atoi(getenv("KNP_FUSED_LEVELS")) == 0;
+            if (!used || off || lvl_off || H.fused || H.cheby != 1 || H.pre != 1 || H.post != 1 || !L.S_rp || L.S_rows != L.n || L.S_n_act > 0 ||
+                L.n_coarse <= 0 || L.A_nnz <= 0 || !L.inv_diag) continue;
+            KCHK(build_level_scaled(ctx, h, l));
+            L.lfused = 1;
+        }
     }
     if (kind == KNP_PC_VBJACOBI && ctx->have_A) {
         const KnpHostGraph& g = ctx->g;
@@ -4106,6 +4156,10 @@ int knp_get_stats(const knp_ctx* ctx, double* out) {
     out[KNP_ST_FUSED] = (double)(ctx->hier[0].fused + 2 * ctx->hier[1].fused + 4 * ctx->hier[0].l0_fused + 8 * ctx->hier[1].l0_fused);
     out[KNP_ST_NORM_FALLBACK] = (double)ctx->n_norm_fallback;
     out[KNP_ST_BLOCKED] = (double)(ctx->hier[0].blocked + 2 * ctx->hier[1].blocked);
+    int nlf = 0;
+    for (int h = 0; h < KNP_MAX_HIER; ++h)
+        for (int l = 1; l < ctx->hier[h].levels; ++l) nlf += ctx->hier[h].lv[l].lfused;
+    out[KNP_ST_FUSED_LEVELS] = (double)nlf;
     return KNP_OK;
 }
 

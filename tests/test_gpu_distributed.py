@@ -47,7 +47,7 @@ def _worker(rank, size, port, q, rtol=1e-13, extra=None, N=16, kind="square", pc
         nvo = lm.n_vertices_owned
         phim = s.problem.phi_m_prev.numpy()
         q.put((rank, "ok", ni, ne, lm.l2g[:nvo].copy(), phim[:nvo].copy(), list(s.iterations), s.backend.n_dof_global,
-               bool(getattr(s.backend, "p2p_on", False)), s.backend.stats()["fused"]))
+               bool(getattr(s.backend, "p2p_on", False)), s.backend.stats()["fused"], s.backend.stats()["fused_levels"]))
         dist.barrier()
         dist.destroy_process_group()
     except Exception:      # noqa: BLE001
@@ -88,6 +88,8 @@ def test_global_amg_keeps_single_gpu_iteration_counts(extra, N, kind, pc, max_it
         assert max(r[6]) <= max_its, r[6]
         assert abs(r[2] - oi) <= 2e-6 * oi
         assert r[9] & 4 and (pc != "btcc" or r[9] & 8), "level 0 of the distributed hierarchies must run in fused form"
+        if extra.get("amg_replicate_below") == 60:
+            assert r[10] >= 1, "the distributed level below level 0 must run in fused form (At down-leg, S up-leg)"
 
 
 @pytest.mark.parametrize("size,comm", [(2, "p2p"), (2, "hooks"), (4, "p2p")])
