@@ -1,4 +1,4 @@
-"""Developer tool: dump A, P, b of the MMS problem (run on a GPU box from the repo root): python tools/dump_mms.py 2 32"""
+"""Developer tool: dump A, P, b of the MMS problem (run on a GPU box from the repo root): python tests/devtools/dump_mms.py 2 32"""
 import sys; sys.path.insert(0, 'tests'); import conftest  # noqa
 import numpy as np, scipy.sparse as sp
 from parity_utils import mms_config

@@ -1,4 +1,4 @@
-"""Developer tool: MMS run with solver settings from the command line: python tools/mms_try.py 2 32 amg_setup=host ..."""
+"""Developer tool: MMS run with solver settings from the command line: python tests/devtools/mms_try.py 2 32 amg_setup=host ..."""
 import sys; sys.path.insert(0, 'tests'); import conftest  # noqa
 import numpy as np
 from parity_utils import mms_config

@@ -363,7 +363,7 @@ def test_node_synchronised_aggregation_shares_patterns_between_fields():
 
 def test_node_synchronised_aggregation_declines_an_indefinite_potential_block():
     """P of the MMS problem on the 32x32 square (tests/golden/mms_P_square32.npz, assembled by the HIP path and dumped with
-    tools/dump_mms.py): non-dimensional constants make the membrane mass of the potential block (minus sign in the
+    tests/devtools/dump_mms.py): non-dimensional constants make the membrane mass of the potential block (minus sign in the
     reference's form, KNPEMIx_problem.py:657-744) larger than its stiffness, the diagonal turns negative on membrane nodes.
     Following the ion aggregates there gives a V-cycle with eigenvalues of both signs (GMRES then stalls: 2000 iterations
     on the GPU); both builders must fall back to the unsynchronised aggregation for such a matrix."""
