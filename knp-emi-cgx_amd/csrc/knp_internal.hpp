@@ -302,6 +302,7 @@ struct knp_ctx {
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     const double* prep_b = nullptr;
+    int prep_fused = 0;   // the side-stream ||B b|| used the one-reduction projected norm (flag in slot 61)
     // statistics of the solves (knp_get_stats): ||B b|| of the last solve, exchanges and host read-backs since the last reset
     double last_bnorm = 0.0;
     int64_t n_allreduce = 0, n_halo = 0, n_readback = 0;

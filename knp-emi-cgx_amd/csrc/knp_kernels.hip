@@ -1512,6 +1512,30 @@ __global__ void __launch_bounds__(NT) k_scale_rsqrt(int n, const double* __restr
     const double inv = 1.0 / sqrt(*nrm2);
     for (int e = blockIdx.x * NT + threadIdx.x; e < n; e += gridDim.x * NT) out[e] = in[e] * inv;
 }
+// out = (in - mean on the potential entries) / sqrt(*nrm2), mean = *phi_sum * inv_count: the gauge projection and the normalisation
+// of the initial Krylov vector in one pass (pc_apply_norm left the vector unprojected)
+__global__ void __launch_bounds__(NT) k_scale_rsqrt_proj(int n, const double* __restrict__ in, const double* __restrict__ nrm2,
+                                                         const double* __restrict__ phi_sum, double inv_count, double* __restrict__ out) {
+    const double inv = 1.0 / sqrt(*nrm2);
+    const double mean = (*phi_sum) * inv_count;
+    for (int e = blockIdx.x * NT + threadIdx.x; e < n; e += gridDim.x * NT) out[e] = ((e & 3) == 3 ? in[e] - mean : in[e]) * inv;
+}
+// red[out] = |z - ns (ns.z)|^2 = z.z - s^2/cnt from the reduced {s = sum of the potential entries, z.z} (Pythagoras); flag 1 when
+// that difference has lost half of its digits (the caller then projects explicitly and reduces again, cf. GM_CANCEL)
+__global__ void k_proj_norm(double* __restrict__ red, int slot_s, int slot_out, double inv_count, double cancel, double* mirror,
+                            volatile int64_t* seq, int64_t seq_val) {
+    if (threadIdx.x != 0) return;
+    const double s = red[slot_s], ww = red[slot_s + 1];
+    const double nrm2 = ww - s * s * inv_count;
+    const bool bad = !(nrm2 > cancel * ww) && ww > 0.0;
+    red[slot_out] = bad ? ww : nrm2;
+    red[slot_out + 1] = bad ? 1.0 : 0.0;
+    if (mirror) { mirror[slot_out] = red[slot_out]; mirror[slot_out + 1] = red[slot_out + 1]; }
+    if (seq) {
+        __threadfence_system();
+        *seq = seq_val;
+    }
+}
 
 // x += sum_i y[i] V_i
 __global__ void __launch_bounds__(NT) k_lincomb(int n, int64_t ldv, int m, const double* __restrict__ V,
@@ -3876,6 +3900,44 @@ static bool exchanges_all_native(const knp_ctx* ctx) {
     return true;
 }
 
+// z = B r and the squared norm of its gauge-projected part with ONE reduction: {sum of the potential entries, z.z} are reduced
+// together and |z - ns (ns.z)|^2 = z.z - s^2/cnt (k_proj_norm; slot 60 = the norm, 61 = its cancellation flag, 62 = s).  z itself is
+// left UNPROJECTED (*fused = true): the caller subtracts the mean when it normalises (k_scale_rsqrt_proj) or does not need z at
+// all (||B b||).  Without a null space: the plain sequence, *fused = false.
+static int pc_apply_norm(knp_ctx* ctx, const double* r, double* z, int64_t cnt, bool* fused) {
+    static const bool off = getenv("KNP_NO_FUSED_NORM") != nullptr;
+    if (!(ctx->ns_on && cnt > 0) || off || ctx->defl_m > 0) {
+        *fused = false;
+        KCHK(pc_apply_proj(ctx, r, z, cnt));
+        return dot_to_slot(ctx, z, z, 60);
+    }
+    *fused = true;
+    KCHK(pc_apply_proj(ctx, r, z, 0));
+    ProfScope ps(ctx, 1);
+    const int nb = ctx->n_red_blocks;
+    hipLaunchKernelGGL((k_multi_dot<8, true, true>), dim3(nb), dim3(NT), 0, ctx->stream, ctx->n_dof_owned, (int64_t)ctx->n_dof_local, 0, 0,
+                       ctx->d_V, z, ctx->d_partial);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(2), dim3(NT), 0, ctx->stream, nb, ctx->d_partial, ctx->d_red, 62, (double*)nullptr);
+    KCHK(allreduce_slots(ctx, 62, 2));
+    hipLaunchKernelGGL(k_proj_norm, dim3(1), dim3(64), 0, ctx->stream, ctx->d_red, 62, 60, 1.0 / (double)cnt, GM_CANCEL, ctx->mirror(),
+                       ctx->mirror() ? ctx->h_seq_dev : nullptr, ++ctx->seq_counter);
+    HIPCHK(hipGetLastError());
+    return KNP_OK;
+}
+// the host side of it: read {norm^2, flag}; on cancellation project z explicitly and reduce again (*fused becomes false)
+static int pc_norm_read(knp_ctx* ctx, double* z, int64_t cnt, bool* fused) {
+    KCHK(read_slots(ctx, 60, *fused ? 2 : 1, ctx->seq_counter));
+    if (*fused && ctx->h_red[61] != 0.0) {
+        ++ctx->n_norm_fallback;
+        const int no = ctx->g.n_nodes_owned;
+        hipLaunchKernelGGL(k_phi_sub, dim3(nblocks(no)), dim3(NT), 0, ctx->stream, no, ctx->d_red + 62, 1.0 / (double)cnt, z);
+        *fused = false;
+        KCHK(dot_to_slot(ctx, z, z, 60));
+        KCHK(read_slots(ctx, 60, 1, ctx->seq_counter));
+    }
+    return KNP_OK;
+}
+
 int knp_gmres_prepare(knp_ctx* ctx, const double* b) {
     CHECK_CTX(ctx);
     if (!b) return KNP_E_ARG;
@@ -3902,8 +3964,9 @@ int knp_gmres_prepare(knp_ctx* ctx, const double* b) {
     HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
     hipStream_t main_stream = ctx->stream;
     ctx->stream = ctx->stream2;
-    rc = pc_apply_proj(ctx, b, ctx->d_w, cnt);
-    if (rc == KNP_OK) rc = dot_to_slot(ctx, ctx->d_w, ctx->d_w, 60);
+    bool fused_norm = false;
+    rc = pc_apply_norm(ctx, b, ctx->d_w, cnt, &fused_norm);
+    ctx->prep_fused = fused_norm ? 1 : 0;
     ctx->stream = main_stream;
     KCHK(rc);
     HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
@@ -3960,13 +4023,19 @@ int knp_gmres_solve(knp_ctx* ctx, const double* b, double* x, double rtol, doubl
         HIPCHK(hipEventSynchronize(ctx->ev_join));
         ctx->prep_b = nullptr;
         if (!ctx->h_red_dev) {
-            HIPCHK(hipMemcpy(ctx->h_red + 60, ctx->d_red + 60, sizeof(double), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(ctx->h_red + 60, ctx->d_red + 60, 2 * sizeof(double), hipMemcpyDeviceToHost));
+        }
+        if (ctx->prep_fused && ctx->h_red[61] != 0.0) {   // cancellation in the one-reduction norm: redo it explicitly, in line
+            ++ctx->n_norm_fallback;
+            KCHK(pc_apply_proj(ctx, b, ctx->d_w, cnt));
+            KCHK(dot_to_slot(ctx, ctx->d_w, ctx->d_w, 60));
+            KCHK(read_slots(ctx, 60, 1, ctx->seq_counter));
         }
     } else {
         side_discard(ctx);
-        KCHK(pc_apply_proj(ctx, b, ctx->d_w, cnt));
-        KCHK(dot_to_slot(ctx, ctx->d_w, ctx->d_w, 60));
-        KCHK(read_slots(ctx, 60, 1, ctx->seq_counter));
+        bool fused_norm = false;
+        KCHK(pc_apply_norm(ctx, b, ctx->d_w, cnt, &fused_norm));
+        KCHK(pc_norm_read(ctx, ctx->d_w, cnt, &fused_norm));
     }
     const double bnorm = std::sqrt(ctx->h_red[60]);
     ctx->last_bnorm = bnorm;
@@ -3982,16 +4051,20 @@ int knp_gmres_solve(knp_ctx* ctx, const double* b, double* x, double rtol, doubl
     while (true) {
         // r = M (b - A x)
         KCHK(spmv_A(ctx, x, b, ctx->d_t, true));
-        KCHK(pc_apply_proj(ctx, ctx->d_t, ctx->d_w, cnt));
-        KCHK(dot_to_slot(ctx, ctx->d_w, ctx->d_w, 60));
-        KCHK(read_slots(ctx, 60, 1, ctx->seq_counter));
+        bool fused_norm = false;   // the gauge projection of r rides on the norm's reduction and on the normalisation pass
+        KCHK(pc_apply_norm(ctx, ctx->d_t, ctx->d_w, cnt, &fused_norm));
+        KCHK(pc_norm_read(ctx, ctx->d_w, cnt, &fused_norm));
         const double beta = std::sqrt(ctx->h_red[60]);
         res = beta;
         if (res0 < 0) res0 = beta;
         if (!std::isfinite(beta)) { *reason = KNP_DIVERGED_NANORINF; break; }
         if (beta <= ttol) { *reason = (beta <= atol) ? KNP_CONVERGED_ATOL : KNP_CONVERGED_RTOL; break; }
         if (it >= max_it) { *reason = KNP_DIVERGED_ITS; break; }
-        hipLaunchKernelGGL(k_scale_rsqrt, dim3(vec_blocks), dim3(NT), 0, st, n, ctx->d_w, ctx->d_red + 60, ctx->d_V);
+        if (fused_norm)
+            hipLaunchKernelGGL(k_scale_rsqrt_proj, dim3(vec_blocks), dim3(NT), 0, st, n, ctx->d_w, ctx->d_red + 60, ctx->d_red + 62,
+                               1.0 / (double)cnt, ctx->d_V);
+        else
+            hipLaunchKernelGGL(k_scale_rsqrt, dim3(vec_blocks), dim3(NT), 0, st, n, ctx->d_w, ctx->d_red + 60, ctx->d_V);
         hipLaunchKernelGGL(k_gm_init, dim3(1), dim3(64), 0, st, GL, gm, ctx->d_red + 60);
         int jd = 0;
         bool stop = false;
