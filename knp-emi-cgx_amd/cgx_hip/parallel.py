@@ -14,6 +14,7 @@ Gram-Schmidt coefficients.  Both are invoked by libknpemi_hip through the two ho
 """
 from __future__ import annotations
 
+import os
 import traceback
 from dataclasses import dataclass, field
 
@@ -77,11 +78,14 @@ class LocalMesh:
     defl: dict | None = None
 
 
-def vertex_partition(coords, size, method=None):
+def vertex_partition(coords, size, method=None, weights=None):
     """Owner rank of every vertex.  ``rcb`` (default): recursive coordinate bisection -- the vertex set is cut at the
     (size-proportional) median along its longest axis, recursively, which gives compact subdomains with small
     interfaces (the geometric stand-in for the reference's METIS/ParMETIS partition of the dual graph; neither is
-    available here).  ``slab``: 1-D slabs along the longest axis.  Deterministic; ``KNP_PARTITION`` overrides."""
+    available here).  ``slab``: 1-D slabs along the longest axis.  Deterministic; ``KNP_PARTITION`` overrides.
+    ``weights`` (per vertex, > 0): the cuts balance the weight instead of the vertex count -- ``partition_mesh`` passes the
+    number of unknowns a vertex carries (membrane vertices have an intra- and an extracellular node: twice the rows, plus
+    the facet quadrature), the analogue of the vertex weights one would hand to METIS for these meshes."""
     import os
     n = coords.shape[0]
     if size == 1:
@@ -94,10 +98,17 @@ def vertex_partition(coords, size, method=None):
         keys = tuple(coords[idx, k] for k in range(dim)) + (coords[idx, ax],)
         return idx[np.lexsort(keys)]
     owner = np.empty(n, dtype=np.int32)
+    w = None if weights is None else np.asarray(weights, dtype=np.float64)
+    if w is not None and (w.shape != (n,) or not (w > 0).all()):
+        raise ValueError("vertex weights must be positive, one per vertex")
     if method == "slab":
         ext = coords.max(axis=0) - coords.min(axis=0)
         order = sorted_along(np.arange(n), int(np.argmax(ext)))
-        bounds = np.linspace(0, n, size + 1).astype(np.int64)
+        if w is None:
+            bounds = np.linspace(0, n, size + 1).astype(np.int64)
+        else:
+            cw = np.cumsum(w[order])
+            bounds = np.concatenate([[0], np.searchsorted(cw, cw[-1] * np.arange(1, size) / size, side="left") + 1, [n]]).astype(np.int64)
         for r in range(size):
             owner[order[bounds[r]:bounds[r + 1]]] = r
         return owner
@@ -110,7 +121,12 @@ def vertex_partition(coords, size, method=None):
         ext = coords[idx].max(axis=0) - coords[idx].min(axis=0)
         order = sorted_along(idx, int(np.argmax(ext)))
         left = parts // 2
-        cut = int(round(len(order) * left / parts))
+        if w is None:
+            cut = int(round(len(order) * left / parts))
+        else:
+            cw = np.cumsum(w[order])
+            cut = int(np.searchsorted(cw, cw[-1] * left / parts, side="left")) + 1
+            cut = min(max(cut, 1), len(order) - 1) if len(order) > 1 else len(order)
         stack.append((order[:cut], r0, left))
         stack.append((order[cut:], r0 + left, parts - left))
     return owner
@@ -166,7 +182,17 @@ def extract_local(coords, cells, cell_tags, gamma, gamma_tags, vertex_owner, ran
 
 
 def partition_mesh(coords, cells, cell_tags, gamma, gamma_tags, size, rank, intra_tags=None, max_modes=32) -> LocalMesh:
-    owner = vertex_partition(coords, size)
+    wts = None
+    if size > 1 and intra_tags is not None and os.environ.get("KNP_PARTITION_WEIGHTS", "1") != "0":
+        # unknowns per vertex: one node per side the vertex touches (membrane vertices: two)
+        is_i = np.isin(cell_tags, intra_tags)
+        touch_i = np.zeros(coords.shape[0], dtype=bool)
+        touch_e = np.zeros(coords.shape[0], dtype=bool)
+        touch_i[np.asarray(cells)[is_i].ravel()] = True
+        touch_e[np.asarray(cells)[~is_i].ravel()] = True
+        wts = touch_i.astype(np.float64) + touch_e.astype(np.float64)
+        wts[wts == 0.0] = 1.0
+    owner = vertex_partition(coords, size, weights=wts)
     lm = extract_local(coords, cells, cell_tags, gamma, gamma_tags, owner, rank)
     if size > 1 and intra_tags is not None:
         lm.defl = cut_component_modes(coords, cells, np.isin(cell_tags, intra_tags), gamma, owner, lm.l2g, max_modes)

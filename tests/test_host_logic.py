@@ -395,6 +395,15 @@ def test_recursive_coordinate_bisection_partition():
         e = np.concatenate([cells[:, [a, b]] for a in range(4) for b in range(a + 1, 4)])
         return int((owner[e[:, 0]] != owner[e[:, 1]]).sum())
     assert cut_edges(vertex_partition(coords, 8, "rcb")) < 0.6 * cut_edges(vertex_partition(coords, 8, "slab"))
+    # weighted cuts: vertices in one corner count double (membrane vertices carry two nodes) -> the WEIGHT is balanced
+    w = np.where((coords < 0.4).all(axis=1), 2.0, 1.0)
+    for size in (2, 4, 7):
+        for method in ("rcb", "slab"):
+            o = vertex_partition(coords, size, method, weights=w)
+            load = np.bincount(o, weights=w, minlength=size)
+            assert load.max() - load.min() <= 2.0 * size + 2 and (np.bincount(o, minlength=size) > 0).all()
+            cnt = np.bincount(o, minlength=size)
+            assert cnt.max() - cnt.min() > size, "weights must move the cuts"
 
 
 def test_point_location_and_p1_weights():
