@@ -171,8 +171,19 @@ def _replicate_pattern(Sn: sp.csr_matrix, stride: int, fields, n_dof: int) -> sp
     return out
 
 
+DENSE_LIMIT = 6000      # largest coarsest level that gets a dense pseudo-inverse
+
+
+def _decoupled_rows(A: sp.csr_matrix, diag: np.ndarray) -> np.ndarray:
+    """active rows without any off-diagonal entry: 1x1 blocks of the level operator"""
+    coo = A.tocoo()
+    off = (coo.row != coo.col) & (coo.data != 0.0)
+    cnt = np.bincount(coo.row[off], minlength=A.shape[0])
+    return (diag != 0.0) & (cnt == 0)
+
+
 def build_hierarchy(P: sp.csr_matrix, theta: float = 0.08, max_levels: int = 12, coarse_size: int = 2500,
-                    smooth_prolongator: bool = True, agg_distance=2, node_fields=None) -> Hierarchy:
+                    smooth_prolongator: bool = True, agg_distance=2, node_fields=None, split_decoupled: bool = True) -> Hierarchy:
     """Rows with a zero diagonal are inactive: they get no aggregate (zero rows in the prolongator, zero inverse
     diagonal in the smoother), so a field-restricted P yields a hierarchy of that field class only.
 
@@ -180,7 +191,15 @@ def build_hierarchy(P: sp.csr_matrix, theta: float = 0.08, max_levels: int = 12,
     same graph -- the three ion blocks of P): the aggregation is done ONCE, on the node graph of the first field, and every field
     uses the same aggregates and the same strength pattern.  Prolongators, restrictors, S and all coarse operators then have
     the same sparsity pattern for every field (coarse unknown = nf*aggregate + field index), which lets the library store one
-    column index per node entry with nf values behind it.  The hierarchy is still an ordinary list of scalar CSR levels."""
+    column index per node entry with nf values behind it.  The hierarchy is still an ordinary list of scalar CSR levels.
+
+    ``split_decoupled``: unknowns whose row of the level operator has no off-diagonal entry (after a few levels every
+    intracellular cell of a tissue mesh is ONE aggregate per field, decoupled from everything else in P; Dirichlet rows) are not
+    carried to coarser levels: they get no aggregate and their inverse diagonal is divided by the Chebyshev coefficient of
+    the level, which makes the degree-1 smoothing step solve them exactly (x = c (Dinv / c) b = b / d, residual zero).  When
+    only such unknowns keep a level above ``DENSE_LIMIT`` the others are injected into a last level of their own, so that the
+    coarsest operator is small enough for the dense inverse -- without this a mesh with tens of thousands of cells ends on a
+    level of that many 1x1 blocks plus the extracellular part, smoothed but never solved."""
     A = sp.csr_matrix(P, dtype=np.float64)
     A.sort_indices()
     levels = []
@@ -191,12 +210,25 @@ def build_hierarchy(P: sp.csr_matrix, theta: float = 0.08, max_levels: int = 12,
         dinv = np.where(diag != 0.0, 1.0 / np.where(diag != 0.0, diag, 1.0), 0.0)
         lam = estimate_lambda_max(A, dinv)
         n = A.shape[0]
-        if int((diag != 0.0).sum()) <= coarse_size or len(levels) >= max_levels - 1:
+        active = diag != 0.0
+        iso = _decoupled_rows(A, diag) if split_decoupled else np.zeros(n, dtype=bool)
+        if sync and iso.any():       # a node is split off only if all of its fields are decoupled
+            iso_n = np.logical_and.reduce([iso[f::stride] for f in fields])
+            iso = np.zeros(n, dtype=bool)
+            for f in fields:
+                iso[f::stride] = iso_n
+        n_core = int((active & ~iso).sum())
+        n_all = int(active.sum())
+        if n_all <= coarse_size or n_core == 0 or len(levels) >= max_levels - 1:
             levels.append(Level(A, dinv, lam))
             break
+        # only decoupled unknowns keep this level too large for the dense inverse: the coupled ones move to a level of their own
+        inject = n_core <= coarse_size and n_all > DENSE_LIMIT
+        if iso.any():
+            dinv = np.where(iso, dinv / cheby_first_coefficient(lam), dinv)
+            active = active & ~iso
         # strength threshold decays with the level (Galerkin operators of smoothed aggregation get denser and
         # their entries more uniform; a fixed threshold stalls the coarsening in 3D)
-        active = diag != 0.0
         if sync:
             # node graph of the first field; aggregates of nodes; every field follows them
             nf = len(fields)
@@ -213,10 +245,12 @@ def build_hierarchy(P: sp.csr_matrix, theta: float = 0.08, max_levels: int = 12,
                 for f in fields[1:]:
                     Sf = strength_graph(A[f::stride][:, f::stride].tocsr(), theta)
                     if np.any((np.diff(Sf.indptr) == 0) & (deg0 > 0)) or np.any((diag[f::stride] <= 0.0) & (diag[fields[0]::stride] > 0.0)):
-                        return build_hierarchy(P, theta, max_levels, coarse_size, smooth_prolongator, agg_distance, None)   # unsynchronised
+                        return build_hierarchy(P, theta, max_levels, coarse_size, smooth_prolongator, agg_distance, None, split_decoupled)   # unsynchronised
             act_n = active[fields[0]::stride]
             ian = np.nonzero(act_n)[0]
-            if act_n.all():
+            if inject:
+                agg_n, nagg_n = np.arange(ian.size), int(ian.size)
+            elif act_n.all():
                 agg_n, nagg_n = aggregate(Sn, seed=len(levels), distance=_dist(agg_distance, len(levels)))
             else:
                 agg_n, nagg_n = aggregate(Sn[ian][:, ian].tocsr(), seed=len(levels), distance=_dist(agg_distance, len(levels)))
@@ -226,18 +260,21 @@ def build_hierarchy(P: sp.csr_matrix, theta: float = 0.08, max_levels: int = 12,
             nagg = nf * nagg_n
         else:
             S = strength_graph(A, theta * 0.25 ** len(levels))
-            if active.all():
+            if inject:
+                rows_t = np.nonzero(active)[0]
+                agg, nagg = np.arange(rows_t.size), int(rows_t.size)
+            elif active.all():
                 agg, nagg = aggregate(S, seed=len(levels), distance=_dist(agg_distance, len(levels)))
                 rows_t = np.arange(n)
             else:
                 ia = np.nonzero(active)[0]
                 agg, nagg = aggregate(S[ia][:, ia].tocsr(), seed=len(levels), distance=_dist(agg_distance, len(levels)))
                 rows_t = ia
-        if nagg >= 0.9 * rows_t.size:                         # coarsening stalled
+        if nagg >= 0.9 * rows_t.size and not inject:          # coarsening stalled
             levels.append(Level(A, dinv, lam))
             break
         T = sp.csr_matrix((np.ones(rows_t.size), (rows_t, agg)), shape=(n, nagg))
-        if smooth_prolongator:
+        if smooth_prolongator and not inject:
             # filtered matrix: weak off-diagonals lumped onto the diagonal
             Sp = S + sp.identity(n, format="csr")
             AF = A.multiply(Sp).tocsr()
@@ -260,7 +297,7 @@ def build_hierarchy(P: sp.csr_matrix, theta: float = 0.08, max_levels: int = 12,
         A = Ac
         if sync:
             stride, fields = len(fields), tuple(range(len(fields)))      # coarse unknowns: nf * aggregate + field index
-    coarse_inv = dense_pseudo_inverse(levels[-1].A) if levels[-1].A.shape[0] <= 6000 else None
+    coarse_inv = dense_pseudo_inverse(levels[-1].A) if levels[-1].A.shape[0] <= DENSE_LIMIT else None
     h = Hierarchy(levels, coarse_inv)
     h.node_fields = len(node_fields[1]) if sync else 0                   # > 0: same pattern for every field on every level
     return h

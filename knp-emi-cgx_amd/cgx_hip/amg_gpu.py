@@ -177,9 +177,11 @@ def _aggregate(crow, col, n, seed, distance):
     return agg, nagg
 
 
-def build_hierarchy(P, theta: float = 0.08, max_levels: int = 12, coarse_size: int = 2500, agg_distance=2, device="cuda", node_fields=None):
+def build_hierarchy(P, theta: float = 0.08, max_levels: int = 12, coarse_size: int = 2500, agg_distance=2, device="cuda", node_fields=None,
+                    split_decoupled: bool = True):
     """Device version of ``amg.build_hierarchy`` (same arguments, same kind of result; ``node_fields``: aggregation on the node
-    graph of the first field, shared by all fields -- see amg.build_hierarchy)."""
+    graph of the first field, shared by all fields; ``split_decoupled``: unknowns without off-diagonal entries are solved by the
+    smoother and not carried to coarser levels -- see amg.build_hierarchy)."""
     A = _from_scipy(P, device)
     A_host = sp.csr_matrix(P, dtype=np.float64)
     A_host.sort_indices()
@@ -192,10 +194,29 @@ def build_hierarchy(P, theta: float = 0.08, max_levels: int = 12, coarse_size: i
         active = diag != 0
         dinv = torch.where(active, 1.0 / torch.where(active, diag, torch.ones_like(diag)), torch.zeros_like(diag))
         lam = _lambda_max(A, dinv)
-        n_act = int(active.sum())
-        if n_act <= coarse_size or len(levels) >= max_levels - 1:
+        iso = torch.zeros(n, dtype=torch.bool, device=diag.device)
+        if split_decoupled:
+            r_a, c_a, v_a = A.rows(), A.col, A.val
+            offd = (r_a != c_a) & (v_a != 0)
+            iso = active & (torch.bincount(r_a[offd], minlength=n) == 0)
+            if sync and bool(iso.any()):       # a node is split off only if all of its fields are decoupled
+                iso_n = iso[fields[0]::stride].clone()
+                for f in fields[1:]:
+                    iso_n &= iso[f::stride]
+                iso = torch.zeros(n, dtype=torch.bool, device=diag.device)
+                for f in fields:
+                    iso[f::stride] = iso_n
+        any_iso = bool(iso.any())
+        n_core = int((active & ~iso).sum())
+        n_all = int(active.sum())
+        if n_all <= coarse_size or n_core == 0 or len(levels) >= max_levels - 1:
             levels.append(amg.Level(A_host, dinv.cpu().numpy(), lam))
             break
+        inject = n_core <= coarse_size and n_all > amg.DENSE_LIMIT
+        if any_iso:
+            dinv = torch.where(iso, dinv / amg.cheby_first_coefficient(lam), dinv)
+            active = active & ~iso
+        n_act = n_core
         th = theta * 0.25 ** len(levels)
         if sync:
             # node graph of the first field -> aggregates of nodes -> the same aggregates and strength pattern for every field
@@ -211,11 +232,13 @@ def build_hierarchy(P, theta: float = 0.08, max_levels: int = 12, coarse_size: i
                     Af = _from_coo(torch.div(r_[mf], stride, rounding_mode="floor"), torch.div(c_[mf], stride, rounding_mode="floor"), v_[mf], (nn, nn))
                     degf = torch.bincount(torch.div(_strength(Af, th), nn, rounding_mode="floor"), minlength=nn)
                     if bool(((degf == 0) & (deg0 > 0)).any()) or bool(((diag[f::stride] <= 0) & (diag[f0::stride] > 0)).any()):
-                        return build_hierarchy(P, theta, max_levels, coarse_size, agg_distance, device, None)
+                        return build_hierarchy(P, theta, max_levels, coarse_size, agg_distance, device, None, split_decoupled)
             act_n = active[f0::stride]
             ian = torch.nonzero(act_n).squeeze(1)
             n_act_n = int(ian.numel())
-            if n_act_n == nn:
+            if inject:
+                agg_n, nagg_n = torch.arange(n_act_n, device=diag.device), n_act_n
+            elif n_act_n == nn:
                 crow_s, col_s = _pattern_csr(skey_n, nn)
                 agg_n, nagg_n = _aggregate(crow_s, col_s, nn, len(levels), amg._dist(agg_distance, len(levels)))
             else:
@@ -235,7 +258,9 @@ def build_hierarchy(P, theta: float = 0.08, max_levels: int = 12, coarse_size: i
             skey = _strength(A, th)
             # aggregation on the active sub-graph
             ia = torch.nonzero(active).squeeze(1)
-            if n_act == n:
+            if inject:
+                agg, nagg = torch.arange(n_act, device=diag.device), n_act
+            elif n_act == n:
                 crow_s, col_s = _pattern_csr(skey, n)
                 agg, nagg = _aggregate(crow_s, col_s, n, len(levels), amg._dist(agg_distance, len(levels)))
             else:
@@ -246,7 +271,7 @@ def build_hierarchy(P, theta: float = 0.08, max_levels: int = 12, coarse_size: i
                 sub = newid[rr[both]] * n_act + newid[cc[both]]
                 crow_s, col_s = _pattern_csr(sub, n_act)
                 agg, nagg = _aggregate(crow_s, col_s, n_act, len(levels), amg._dist(agg_distance, len(levels)))
-        if nagg >= 0.9 * n_act:
+        if nagg >= 0.9 * n_act and not inject:
             levels.append(amg.Level(A_host, dinv.cpu().numpy(), lam))
             break
         dev = A.val.device
@@ -267,12 +292,15 @@ def build_hierarchy(P, theta: float = 0.08, max_levels: int = 12, coarse_size: i
         dF = AF.diagonal()
         okF = dF != 0
         dFinv = torch.where(okF, 1.0 / torch.where(okF, dF, torch.ones_like(dF)), torch.zeros_like(dF))
-        lamF = _lambda_max(AF, dFinv, iters=15)
-        omega = 4.0 / (3.0 * lamF)
-        AFT = _spgemm(AF, T)
-        rAFT = AFT.rows()
-        Pm = _from_coo(torch.cat([T.rows(), rAFT]), torch.cat([T.col, AFT.col]),
-                       torch.cat([T.val, -omega * dFinv[rAFT] * AFT.val]), (n, nagg), drop_zeros=True)
+        if inject:
+            Pm = T                                           # the coupled unknowns move to a level of their own, unchanged
+        else:
+            lamF = _lambda_max(AF, dFinv, iters=15)
+            omega = 4.0 / (3.0 * lamF)
+            AFT = _spgemm(AF, T)
+            rAFT = AFT.rows()
+            Pm = _from_coo(torch.cat([T.rows(), rAFT]), torch.cat([T.col, AFT.col]),
+                           torch.cat([T.val, -omega * dFinv[rAFT] * AFT.val]), (n, nagg), drop_zeros=True)
         R = _transpose(Pm)
         AP = _spgemm(A, Pm)
         Ac = _spgemm(R, AP)
@@ -288,7 +316,7 @@ def build_hierarchy(P, theta: float = 0.08, max_levels: int = 12, coarse_size: i
     # the dense pseudo-inverse stays on the host (LAPACK): the device eigen-solver is not accurate enough for the nearly
     # singular potential block (residual |A A+ A - A| of 0.2-0.4 instead of 1e-13 on MI355X / ROCm 7.2)
     last = levels[-1].A
-    coarse_inv = amg.dense_pseudo_inverse(last) if last.shape[0] <= 6000 else None
+    coarse_inv = amg.dense_pseudo_inverse(last) if last.shape[0] <= amg.DENSE_LIMIT else None
     h = amg.Hierarchy(levels, coarse_inv)
     h.node_fields = len(node_fields[1]) if sync else 0
     return h

@@ -84,6 +84,7 @@ class SolverKNPEMI:
     amg_replicate_below = 300000
     amg_fp32 = True        # mixed-precision preconditioner storage (operators fp32, vectors/Krylov fp64)
     amg_node_sync = True   # ion hierarchy: aggregate NODES once, all three ion fields share aggregates and sparsity patterns
+    amg_split_decoupled = True   # unknowns without off-diagonal entries on a level are solved by its smoother, not coarsened further
     _b_is_final = False
     amg_setup = "gpu"      # where the hierarchy is built: "gpu" (torch sparse products, cgx_hip/amg_gpu.py) | "host" (SciPy)
 
@@ -114,7 +115,7 @@ class SolverKNPEMI:
             if "ksp_max_it" in ks: self.ksp_max_it = int(ks["ksp_max_it"])
             if "gmres_restart" in ks: self.gmres_restart = int(ks["gmres_restart"])
             if "strict" in ks: self.strict = bool(ks["strict"])
-            for k in ("amg_theta", "amg_cheby_degree", "amg_pre", "amg_post", "amg_coarse_size", "amg_replicate_below", "amg_fp32", "amg_setup", "amg_node_sync"):
+            for k in ("amg_theta", "amg_cheby_degree", "amg_pre", "amg_post", "amg_coarse_size", "amg_replicate_below", "amg_fp32", "amg_setup", "amg_node_sync", "amg_split_decoupled"):
                 if k in ks: setattr(self, k, type(getattr(self, k))(ks[k]))
         if self.ksp_type != "gmres":
             raise NotImplementedError(f"ksp_type '{self.ksp_type}': only 'gmres' is implemented natively.")
@@ -171,7 +172,8 @@ class SolverKNPEMI:
                 self.P_ = "device CSR (see Backend.precond_csr)"
                 return
             P = P[:, :be.n_dof_owned].tocsr()          # per-rank block (block-Jacobi across GPUs)
-            host_build = lambda M, nf=None: amg.build_hierarchy(M, theta=self.amg_theta, coarse_size=self.amg_coarse_size, node_fields=nf)
+            host_build = lambda M, nf=None: amg.build_hierarchy(M, theta=self.amg_theta, coarse_size=self.amg_coarse_size, node_fields=nf,
+                                                                split_decoupled=self.amg_split_decoupled)
             if str(self.amg_setup) == "gpu":
                 from . import amg_gpu
 
@@ -179,7 +181,8 @@ class SolverKNPEMI:
                     # the setup is host logic either way (the V-cycle always runs in the library): if torch's sparse
                     # products are not usable on this installation, build the same hierarchy with SciPy
                     try:
-                        return amg_gpu.build_hierarchy(M, theta=self.amg_theta, coarse_size=self.amg_coarse_size, device=be.device, node_fields=nf)
+                        return amg_gpu.build_hierarchy(M, theta=self.amg_theta, coarse_size=self.amg_coarse_size, device=be.device, node_fields=nf,
+                                                       split_decoupled=self.amg_split_decoupled)
                     except (RuntimeError, NotImplementedError) as exc:
                         self.print(f"device-side AMG setup unavailable ({type(exc).__name__}: {exc}); using the host setup")
                         return host_build(M, nf)

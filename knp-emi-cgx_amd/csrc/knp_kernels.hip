@@ -3145,12 +3145,15 @@ int knp_amg_reset(knp_ctx* ctx, int32_t hier, int32_t n_levels, int32_t pre, int
     return KNP_OK;
 }
 // compact row list of a prolongator when a good part of its rows is empty
-static int build_act_rows(knp_ctx* ctx, int n_rows, const int32_t* rp_in, int32_t** d_rows, int32_t** d_rp, int* n_act) {
+// ``keep`` (optional, one per row): rows that must stay in the list although their matrix row is empty -- for S these are the
+// unknowns the smoother solves on its own (non-zero inverse diagonal, no interpolation: decoupled 1x1 blocks, Dirichlet rows)
+static int build_act_rows(knp_ctx* ctx, int n_rows, const int32_t* rp_in, int32_t** d_rows, int32_t** d_rp, int* n_act,
+                          const double* keep = nullptr) {
     dev_free(*d_rows); dev_free(*d_rp);
     *n_act = 0;
     std::vector<int32_t> rows, rp(1, 0);
     for (int r = 0; r < n_rows; ++r)
-        if (rp_in[r + 1] > rp_in[r]) { rows.push_back(r); rp.push_back(rp_in[r + 1]); }
+        if (rp_in[r + 1] > rp_in[r] || (keep && keep[r] != 0.0)) { rows.push_back(r); rp.push_back(rp_in[r + 1]); }
     if ((double)rows.size() > 0.8 * n_rows || rows.empty()) return KNP_OK;   // dense enough: the plain kernel is fine
     // non-empty rows are contiguous in the value array only if no empty row lies between entries -- they are: CSR rows are
     // consecutive, empty rows contribute nothing, so rp of the compact list is the running end pointer
@@ -3270,7 +3273,9 @@ int knp_amg_set_level_smoothed(knp_ctx* ctx, int32_t hier, int32_t level, int32_
         KCHK(dev_upload_raw(ctx, &L.S_v, S_v, (size_t)nnzS));
     }
     L.S_rows = n_rows;
-    KCHK(build_act_rows(ctx, n_rows, S_rp, &L.S_act_rows, &L.S_act_rp, &L.S_n_act));
+    std::vector<double> dinv_host((size_t)n_rows);
+    HIPCHK(hipMemcpy(dinv_host.data(), L.inv_diag, (size_t)n_rows * sizeof(double), hipMemcpyDeviceToHost));
+    KCHK(build_act_rows(ctx, n_rows, S_rp, &L.S_act_rows, &L.S_act_rp, &L.S_n_act, dinv_host.data()));
     L.S_lanes = pick_lanes((double)nnzS / std::max(L.S_n_act > 0 ? L.S_n_act : n_rows, 1), 1);
     const int nf = ctx->hier[hier].node_nf;
     if (nf > 0 && ctx->amg_fp32) KCHK(build_blocked(ctx, nf, n_rows, level == 0 ? 4 : nf, nf, S_rp, S_ci, S_v, &L.bS));

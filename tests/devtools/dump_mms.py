@@ -12,9 +12,8 @@ s = SolverKNPEMI(p, solver_config=p.solver_config)
 s.setup_solver()
 be = s.backend
 p.setup_preconditioner(s.use_block_Jacobi)
-s.assemble_preconditioner()
+be.assemble_precond()
 P = be.precond_csr()
-print("hierarchy", [h.describe() for h in s.hierarchies], "node_fields", [getattr(h, "node_fields", None) for h in s.hierarchies], be.stats())
 be.assemble_rhs(); be.assemble_matrix()
 A = be.csr()
 sp.save_npz("gpurun_out/mms_P.npz", sp.csr_matrix(P)); sp.save_npz("gpurun_out/mms_A.npz", sp.csr_matrix(A))

@@ -380,6 +380,57 @@ def test_node_synchronised_aggregation_declines_an_indefinite_potential_block():
     assert amg.build_hierarchy(amg.restrict_to_fields(P, (0, 1, 2)), node_fields=(4, (0, 1, 2))).node_fields == 3
 
 
+def test_decoupled_unknowns_are_split_off_the_hierarchy(monkeypatch):
+    """Tissue lattice (216 cells, one tag each): after two levels every intracellular cell is one aggregate per field, a 1x1
+    block of the level operator.  ``split_decoupled`` keeps those out of the coarser levels (exact degree-1 smoothing:
+    inverse diagonal divided by the Chebyshev coefficient, zero prolongator row) and injects the rest into a last level that
+    is small enough for the dense inverse; the V-cycle stays the exact inverse on the split-off unknowns.  Host and device
+    builders agree."""
+    import numpy as np
+    import knpemi_oracle as K
+    from cgx_hip import amg, amg_gpu, mesh as M
+    coords, cells, tags, ft, _ = M.load_mesh("tissue3d_13_3_w1.xdmf", "tissue3d_13_3_w1.xdmf", 1e-6)
+    intra = tuple(int(t) for t in np.unique(tags) if t != 1)
+    gam, gt, _ = M.gamma_integration_entities(cells, tags, intra, (1,), "intra")
+    o = K.OracleKNPEMI(coords / 1e-6, cells, tags, intra_tags=intra, extra_tag=1, gamma=gam, gamma_tag=gt,
+                       models=[K.Model("passive", intra)], mesh_conversion_factor=1e-6)
+    Pk = amg.restrict_to_fields(o.assemble_P(), (0, 1, 2))
+    monkeypatch.setattr(amg, "DENSE_LIMIT", 70)          # (the real limit, 6000, is reached by lattices of a few thousand cells)
+    kw = dict(theta=0.08, coarse_size=60, node_fields=(4, (0, 1, 2)))
+    h0 = amg.build_hierarchy(Pk, split_decoupled=False, **kw)
+    h1 = amg.build_hierarchy(Pk, **kw)
+    h2 = amg_gpu.build_hierarchy(Pk, device="cpu", **kw)
+    ncell = len(intra)
+    assert h1.describe()["rows"] == h2.describe()["rows"] and h1.node_fields == 3
+    assert h1.levels[-1].A.shape[0] <= 60 < h0.levels[-1].A.shape[0] and h1.coarse_inv is not None
+    for a, b in zip(h1.levels, h2.levels):
+        assert abs(a.A - b.A).max() <= 1e-12 * abs(a.A).max() and np.abs(a.dinv - b.dinv).max() <= 1e-12 * np.abs(a.dinv).max()
+        if a.P is not None:
+            assert abs(a.P - b.P).max() <= 1e-12 and abs(a.S - b.S).max() <= 1e-12
+    # the level on which the cells have collapsed: 3 * ncell decoupled rows with zero prolongator rows and the scaled inverse diagonal
+    found = False
+    for lv in h1.levels[:-1]:
+        A = lv.A.tocsr()
+        iso = amg._decoupled_rows(A, A.diagonal())
+        if iso.sum() >= 3 * ncell:
+            found = True
+            assert np.diff(lv.P.tocsr().indptr)[iso].max() == 0 and np.diff(lv.S.tocsr().indptr)[iso].max() == 0
+            c = amg.cheby_first_coefficient(lv.lambda_max)
+            assert np.allclose(lv.dinv[iso] * A.diagonal()[iso] * c, 1.0, rtol=1e-13)
+    assert found
+    # same V-cycle quality: GMRES on P itself
+    import scipy.sparse.linalg as spla
+    n = Pk.shape[0]
+    act = Pk.diagonal() != 0
+    b = np.where(act, np.random.default_rng(0).standard_normal(n), 0.0)
+    its = []
+    for h in (h0, h1):
+        V = K.pc_amg_vcycle(h.levels, h.coarse_inv, 1, 1, 1)
+        x, k, _ = K.gmres_left(Pk, b, np.zeros(n), V, rtol=1e-8, max_it=200)
+        its.append(k)
+    assert its[1] <= its[0] + 1, its
+
+
 def test_recursive_coordinate_bisection_partition():
     """General meshes are cut by recursive coordinate bisection: balanced, deterministic, compact (2x2x2 blocks on a
     cube for 8 ranks -> far fewer cut edges than 8 slabs)."""
@@ -462,6 +513,10 @@ def test_hierarchy_setup_invariants(fields):
         G = (R @ (A @ Pm)).tocsr()
         assert abs(G - nxt).max() <= 1e-12 * abs(nxt).max()
         active = A.diagonal() != 0.0
+        dec = amg._decoupled_rows(A.tocsr(), A.diagonal())               # 1x1 blocks: solved by the smoother, not interpolated
+        if dec.any():
+            assert np.allclose(lv.dinv[dec] * A.diagonal()[dec] * amg.cheby_first_coefficient(lv.lambda_max), 1.0, rtol=1e-13)
+        active = active & ~dec
         rows_with_P = np.diff(Pm.indptr) > 0
         assert np.array_equal(rows_with_P, active)                       # inactive fields get no interpolation
         assert (np.diff(nxt.indptr) > 0).all()                           # every coarse unknown is coupled
