@@ -170,6 +170,49 @@ def test_membrane_dominated_surrogate_at_scale():
     assert abs(snaps["norms"][0] - oi) <= 1e-6 * oi
 
 
+def test_many_cells_split_off_the_hierarchy(monkeypatch):
+    """Lattice of 6^3 cells with the dense-inverse limit lowered so that the 3 * 216 collapsed cells alone exceed it (what 13824
+    cells do to the real limit): the decoupled unknowns are solved by the smoother of their level, the extracellular rest is
+    injected into a last level with a dense inverse, both hierarchies run the fused cycle (the ion one node-blocked), and the
+    solve follows the oracle running the same algorithm on hierarchies it builds itself."""
+    from CGx.KNPEMI.KNPEMIx_solver import SolverKNPEMI
+    import knpemi_oracle as K
+    from cgx_hip import amg
+    monkeypatch.setattr(amg, "DENSE_LIMIT", 500)
+    cfg = tissue_config(3, 25, 6, steps=2, rtol=1e-9, pc="btcc", stimulus=True, width=1)
+    cfg["solver"]["ksp_settings"]["amg_coarse_size"] = 150
+    p = make_problem(cfg, "ci")
+    s = SolverKNPEMI(p, solver_config=p.solver_config)
+    s.solve()
+    assert all(r > 0 for r in s.reasons), s.reasons
+    hk, hp = s.hierarchies
+    assert hk.levels[-1].A.shape[0] <= 150 and hk.coarse_inv is not None and hp.coarse_inv is not None
+    dec = [int(amg._decoupled_rows(lv.A.tocsr(), lv.A.diagonal()).sum()) for lv in hk.levels]
+    assert max(dec) >= 3 * 216 and dec[-1] == 0, dec
+    st = s.backend.stats()
+    assert st["fused"] == 3 and st["blocked"] == 1
+    lm = p.local_mesh
+    tags = tuple(cfg["ics_tags"])
+    lo, hi = cfg["stimulus_region"]["range"]
+    o = K.OracleKNPEMI(lm.coords, lm.cells, lm.cell_tags, intra_tags=tags, extra_tag=1, gamma=lm.gamma, gamma_tag=lm.gamma_tags,
+                       models=[K.Model("neuronal_ct", tags), K.Model("hh", tags), K.Model("atp", tags)], mesh_conversion_factor=1.0,
+                       stimulus_tags=tags, stimulus_region=(0, lo * 1e-6, hi * 1e-6))
+
+    def fac(P):
+        hko = amg.fp32_stored(amg.build_hierarchy(amg.restrict_to_fields(P, (0, 1, 2)), theta=s.amg_theta, coarse_size=s.amg_coarse_size,
+                                                  node_fields=s.ion_node_fields()), coarse=True)
+        hpo = amg.fp32_stored(amg.build_hierarchy(amg.restrict_to_fields(P, (3,)), theta=s.amg_theta, coarse_size=s.amg_coarse_size))
+        assert hko.describe()["rows"] == hk.describe()["rows"] and hpo.describe()["rows"] == hp.describe()["rows"]
+        return K.pc_btcc(o, hko, hpo, s.amg_pre, s.amg_post, s.amg_cheby_degree, fused=True)
+    _, its = o.run(2, solver="gmres", pc=fac, rtol=1e-9)
+    assert its == list(s.iterations), (its, s.iterations)
+    gam = (o.lay.node_i >= 0) & (o.lay.node_e >= 0)
+    assert np.allclose(p.phi_m_prev.numpy()[gam], o.phi_m[gam], rtol=1e-6, atol=0.0)
+    oi, oe = o.potential_norms()
+    ni, ne = s.potential_norms()
+    assert abs(ni - oi) <= 1e-6 * oi
+
+
 def test_hundred_steps_hh_surrogate_invariants():
     """BASELINE configs[4] shape (tissue + Hodgkin-Huxley gating, 100 implicit steps) on one GPU: 8^3 cells, one tag each,
     stimulus on the cells of one half.  Invariants the reference states or implies: every solve converges; the sum of the
