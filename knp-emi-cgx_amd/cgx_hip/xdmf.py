@@ -141,7 +141,10 @@ def read_mesh_and_tags(mesh_file, facet_file, ct_name=None, ft_name=None):
     coords = np.ascontiguousarray(coords[:, :dim])          # DOLFINx pads 2D geometry to XYZ in some versions
     if cells.min(initial=0) < 0 or cells.max(initial=0) >= len(coords):
         raise XdmfError(f"{mesh_file}: topology refers to points outside the geometry")
-    # cell tags: an Attribute of the mesh grid itself, or a tag grid with its own list of cells
+    # cell tags: an Attribute of the mesh grid itself, or a tag grid with its own list of cells.  A file whose only grid has
+    # another name (meshio writes "Grid") is taken as "tags under the same hierarchy as the mesh".
+    if ct_name not in mf.grids and len(mf.grids) == 1 and vals0 is not None:
+        ct_name = mesh_grid
     if ct_name == mesh_grid:
         if vals0 is None:
             raise XdmfError(f"{mesh_file}: grid '{mesh_grid}' carries no Attribute with the cell tags")
@@ -160,11 +163,11 @@ def read_mesh_and_tags(mesh_file, facet_file, ct_name=None, ft_name=None):
     # facet tags
     ff = mf if same else XdmfFile(facet_file)
     facet_tags = None
+    if ft_name not in ff.grids and len(ff.grids) == 1:
+        ft_name = next(iter(ff.grids))
     if ft_name in ff.grids:
         fcells, fpts, fvals = ff.grid(ft_name)
         if fvals is not None and fcells.shape[1] == dim:
-            if fpts is not None and ft_name != "mesh" and False:
-                pass
             if not same and ft_name == "mesh" and fpts is not None and (len(fpts) != len(coords) or not np.allclose(fpts[:, :dim], coords)):
                 raise XdmfError(f"{facet_file}: the facet file's points differ from the mesh file's")
             facet_tags = (np.asarray(fcells, dtype=np.int64), np.asarray(fvals, dtype=np.int64))

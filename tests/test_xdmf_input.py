@@ -84,6 +84,19 @@ def test_xdmf_reader_meshio_layout_and_inline_xml(expected):
     assert np.array_equal(ft[0], expected["cu_fv"]) and np.array_equal(ft[1], expected["cu_fval"])
 
 
+def test_xdmf_reader_accepts_a_single_grid_of_any_name(expected, tmp_path):
+    """meshio names its grid "Grid": a file with one grid that carries the tags is read as 'tags under the mesh hierarchy'"""
+    import shutil
+    from cgx_hip import xdmf
+    for stem in ("cube3_mesh", "cube3_facets"):
+        shutil.copy(os.path.join(G, stem + ".h5"), tmp_path / (stem + ".h5"))
+        text = open(os.path.join(G, stem + ".xdmf")).read().replace('Grid Name="mesh"', 'Grid Name="Grid"')
+        (tmp_path / (stem + ".xdmf")).write_text(text)
+    coords, cells, ct, ft = xdmf.read_mesh_and_tags(str(tmp_path / "cube3_mesh.xdmf"), str(tmp_path / "cube3_facets.xdmf"))
+    assert np.array_equal(cells, expected["cu_cells"]) and np.array_equal(ct, expected["cu_ct"])
+    assert np.array_equal(ft[0], expected["cu_fv"]) and np.array_equal(ft[1], expected["cu_fval"])
+
+
 def test_load_mesh_from_xdmf_feeds_the_same_membrane_as_the_arrays(expected):
     """``mesh.load_mesh`` on the XDMF pair gives the arrays, scaled, and the membrane facets derived from the file's facet tags
     (value 4) are the intra/extra interface the generator marks on the same mesh"""
