@@ -231,7 +231,7 @@ struct knp_ctx {
     size_t gamma_lds_set = 0;
     // run-time compiled membrane kernel (knp_jit.cpp); null: the interpreter runs
     void* jit_module = nullptr;
-    void* jit_fn[2] = {nullptr, nullptr};   // [0] 2D, [1] 3D right-hand-side facet kernel
+    void* jit_fn[3] = {nullptr, nullptr, nullptr};   // [0] 2D, [1] 3D right-hand-side facet kernel, [2] 3D with 4 lanes x 9 points per facet
     std::string jit_msg;
     bool progs_dirty = true;
     int max_prog = -1;

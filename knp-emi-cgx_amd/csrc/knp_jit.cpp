@@ -220,7 +220,7 @@ extern "C" int knp_jit_compile_check(const int32_t* code, int32_t n_instr, const
 void knp_jit_release(knp_ctx* ctx) {
     if (ctx->jit_module) (void)hipModuleUnload((hipModule_t)ctx->jit_module);
     ctx->jit_module = nullptr;
-    ctx->jit_fn[0] = ctx->jit_fn[1] = nullptr;
+    ctx->jit_fn[0] = ctx->jit_fn[1] = ctx->jit_fn[2] = nullptr;
 }
 
 // (re)build the native membrane kernel for the programs currently set; on any failure the interpreter stays in charge
@@ -246,8 +246,11 @@ void knp_jit_build(knp_ctx* ctx) {
         ctx->jit_msg = "compiled module lacks the kernels";
         return;
     }
+    hipFunction_t f3m = nullptr;
+    if (hipModuleGetFunction(&f3m, mod, "knp_gamma_vec_3d_many") != hipSuccess) { (void)hipGetLastError(); f3m = nullptr; }
     ctx->jit_module = mod;
     ctx->jit_fn[0] = f2;
     ctx->jit_fn[1] = f3;
+    ctx->jit_fn[2] = f3m;
     ctx->jit_msg = "native";
 }

@@ -427,6 +427,14 @@ static void launch_assemble_nodes(knp_ctx* ctx, const DevParams& P, double* at, 
 // K2: membrane facet quadrature + the membrane-program interpreter (shared with the run-time compiled variant)
 // ------------------------------------------------------------------------------------------
 #include "knp_gamma_facets.inc"
+// 3D: 4 lanes x 9 points per facet instead of 16 x 3 -- the 36 points of the degree-10 rule exactly, where 16 x 3 evaluates 48
+// slots and shuffles over four times the lanes.  Measured on MI355X: 1.5 M facets (tissue surrogate) mechanism currents 4.67 -> 3.36 ms,
+// matrix part 1.82 -> 0.70 ms; 55 k facets (cube 136^3) 162 -> 148 / 79 -> 36 us; 12 k facets (cube 64^3) 45.7 -> 44.2 / 24.3 -> 16.9 us.
+// KNP_GAMMA_MANY=<least number of facets> moves the switch, 0 keeps the 16 x 3 kernels.
+static bool gamma_many(const KnpHostGraph& g) {
+    static const int many_min = getenv("KNP_GAMMA_MANY") ? atoi(getenv("KNP_GAMMA_MANY")) : 1;
+    return g.dim == 3 && g.n_q == 36 && many_min > 0 && g.n_g >= many_min;
+}
 
 // ------------------------------------------------------------------------------------------
 // K2b: membrane coupling entries, one thread per membrane vertex pair
@@ -2739,6 +2747,11 @@ int knp_assemble_matrix(knp_ctx* ctx, const knp_fields* fields) {
                                ctx->d_fv, ctx->d_fmeas, ctx->d_qp, ctx->d_qw, f, 0, ctx->d_coords, ctx->d_gamma_prog,
                                (const int32_t* const*)nullptr, (const int32_t*)nullptr, (const double* const*)nullptr,
                                (const int32_t*)nullptr, 0, 0, ctx->d_fmat, ctx->d_fvec);
+        else if (gamma_many(g))   // 4 lanes x 9 points = the 36 points exactly (see gamma_many)
+            hipLaunchKernelGGL((k_gamma_facets<3, true, false, 4, 9, 64, 1>), dim3((unsigned)(((int64_t)g.n_g * 4 + 63) / 64)), dim3(64), 0, ctx->stream, g.n_g, g.n_q, P,
+                               ctx->d_fv, ctx->d_fmeas, ctx->d_qp, ctx->d_qw, f, 0, ctx->d_coords, ctx->d_gamma_prog,
+                               (const int32_t* const*)nullptr, (const int32_t*)nullptr, (const double* const*)nullptr,
+                               (const int32_t*)nullptr, 0, 0, ctx->d_fmat, ctx->d_fvec);
         else
             hipLaunchKernelGGL((k_gamma_facets<3, true, false, 16, 3, 64, 2>), dim3((unsigned)(((int64_t)g.n_g * 16 + 63) / 64)), dim3(64), 0, ctx->stream, g.n_g, g.n_q, P,
                                ctx->d_fv, ctx->d_fmeas, ctx->d_qp, ctx->d_qw, f, 0, ctx->d_coords, ctx->d_gamma_prog,
@@ -2831,6 +2844,8 @@ int knp_assemble_rhs(knp_ctx* ctx, const knp_fields* fields, double* b) {
         // measured on MI355X (cube64: 12 288 facets x 36 points; square512: 1 024 facets x 6 points): 3 points per lane and 16
         // lanes per facet in 3D (258 -> 170 us vs one point per lane), one point per lane in 2D
         void* jit = ctx->jit_fn[g.dim == 2 ? 0 : 1];
+        const bool many = gamma_many(g) && ctx->jit_fn[2];
+        if (many) jit = ctx->jit_fn[2];
         if (jit) {   // run-time compiled programs (knp_jit.cpp): same kernel source, native mechanism code, no LDS register file
             int n_g = g.n_g, n_q = g.n_q, n_aux_ = n_aux, nr = 0, cc0 = 0;
             DevParams Pp = P;
@@ -2841,7 +2856,7 @@ int knp_assemble_rhs(knp_ctx* ctx, const knp_fields* fields, double* b) {
             const double* const* pk = (const double* const*)ctx->d_prog_consts; const int32_t* pn = ctx->d_prog_nconsts;
             double* fmat = ctx->d_fmat; double* fvec = ctx->d_fvec;
             void* args[] = {&n_g, &n_q, &Pp, &fv, &fmeas, &qp, &qw, &ff, &n_aux_, &coords, &gp, &pc, &pl, &pk, &pn, &nr, &cc0, &fmat, &fvec};
-            const int L = g.dim == 2 ? 8 : 16;
+            const int L = g.dim == 2 ? 8 : many ? 4 : 16;
             HIPCHK(hipModuleLaunchKernel((hipFunction_t)jit, (unsigned)(((int64_t)g.n_g * L + 63) / 64), 1, 1, 64, 1, 1, 0, ctx->stream, args, nullptr));
         } else if (g.dim == 2) GF_LAUNCH(2, 8, 1, 64, 2);
         else GF_LAUNCH(3, 16, 3, 64, 2);
