@@ -231,7 +231,7 @@ int knp_set_nullspace(knp_ctx* ctx, int32_t on);
 int knp_project_nullspace(knp_ctx* ctx, double* v);
 int knp_nullspace_test(knp_ctx* ctx, double* out_norm /* host: ||A ns||_2 */);
 int knp_pc_setup(knp_ctx* ctx, int32_t kind);
-int knp_pc_apply(knp_ctx* ctx, const double* r, double* z);
+int knp_pc_apply(knp_ctx* ctx, const double* r, double* z); /* r, z: [n_dof_local]; distributed contexts overwrite the ghost entries of r (see knp_gmres_solve) */
 /* Additive coarse correction for near-null modes the per-GPU preconditioner blocks cannot see (constants of a
  * potential block on a connected component that the partition cuts): z += Z Einv Z^T r with Z the indicator
  * vectors of the potential DoFs of each mode. node_mode: host [n_nodes_owned], -1 = not deflated.
@@ -282,6 +282,11 @@ int knp_amg_set_precision(knp_ctx* ctx, int32_t fp32_storage);
  * runs: the exchange kernels are then ordered on the side stream on every rank).  Any other call that touches the
  * preconditioner or b joins / discards it. */
 int knp_gmres_prepare(knp_ctx* ctx, const double* b);
+/* GMRES(restart), 1 <= restart <= 55 (the per-iteration reduction carries restart + 2 values in the library's 57 Gram-Schmidt
+ * slots; anything larger is KNP_E_ARG).  b and x are [n_dof_local] device vectors.  On distributed contexts the GHOST entries
+ * [n_dof_owned, n_dof_local) of b -- and of r in knp_pc_apply, b in knp_gmres_prepare -- are OVERWRITTEN by the halo exchange of
+ * the preconditioner's fused level-0 leg although the arguments are const-qualified (the owned entries are never written);
+ * on one GPU n_dof_local == n_dof_owned and nothing is written. */
 int knp_gmres_solve(knp_ctx* ctx, const double* b, double* x, double rtol, double atol, int32_t max_it,
                     int32_t restart, int32_t* its, double* rnorm, int32_t* reason);
 

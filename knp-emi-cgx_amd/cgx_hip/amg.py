@@ -183,7 +183,8 @@ def _decoupled_rows(A: sp.csr_matrix, diag: np.ndarray) -> np.ndarray:
 
 
 def build_hierarchy(P: sp.csr_matrix, theta: float = 0.08, max_levels: int = 12, coarse_size: int = 2500,
-                    smooth_prolongator: bool = True, agg_distance=2, node_fields=None, split_decoupled: bool = True) -> Hierarchy:
+                    smooth_prolongator: bool = True, agg_distance=2, node_fields=None, split_decoupled: bool = True,
+                    smoother_degree: int = 1) -> Hierarchy:
     """Rows with a zero diagonal are inactive: they get no aggregate (zero rows in the prolongator, zero inverse
     diagonal in the smoother), so a field-restricted P yields a hierarchy of that field class only.
 
@@ -199,7 +200,13 @@ def build_hierarchy(P: sp.csr_matrix, theta: float = 0.08, max_levels: int = 12,
     the level, which makes the degree-1 smoothing step solve them exactly (x = c (Dinv / c) b = b / d, residual zero).  When
     only such unknowns keep a level above ``DENSE_LIMIT`` the others are injected into a last level of their own, so that the
     coarsest operator is small enough for the dense inverse -- without this a mesh with tens of thousands of cells ends on a
-    level of that many 1x1 blocks plus the extracellular part, smoothed but never solved."""
+    level of that many 1x1 blocks plus the extracellular part, smoothed but never solved.
+
+    ``smoother_degree`` = the Chebyshev degree the cycle will run with: the split relies on every smoothing step being the damped
+    Jacobi step ``x += c Dinv (b - A x)`` (degree 1: any number of pre/post sweeps then leaves ``b/d`` in place).  The momentum term of
+    a degree >= 2 polynomial overshoots a zero residual, so for those the split is switched off (the unknowns are carried as
+    singletons, as before the split existed)."""
+    split_decoupled = bool(split_decoupled) and int(smoother_degree) == 1
     A = sp.csr_matrix(P, dtype=np.float64)
     A.sort_indices()
     levels = []
@@ -245,7 +252,8 @@ def build_hierarchy(P: sp.csr_matrix, theta: float = 0.08, max_levels: int = 12,
                 for f in fields[1:]:
                     Sf = strength_graph(A[f::stride][:, f::stride].tocsr(), theta)
                     if np.any((np.diff(Sf.indptr) == 0) & (deg0 > 0)) or np.any((diag[f::stride] <= 0.0) & (diag[fields[0]::stride] > 0.0)):
-                        return build_hierarchy(P, theta, max_levels, coarse_size, smooth_prolongator, agg_distance, None, split_decoupled)   # unsynchronised
+                        return build_hierarchy(P, theta, max_levels, coarse_size, smooth_prolongator, agg_distance, None, split_decoupled,
+                                               smoother_degree)   # unsynchronised
             act_n = active[fields[0]::stride]
             ian = np.nonzero(act_n)[0]
             if inject:

@@ -178,10 +178,11 @@ def _aggregate(crow, col, n, seed, distance):
 
 
 def build_hierarchy(P, theta: float = 0.08, max_levels: int = 12, coarse_size: int = 2500, agg_distance=2, device="cuda", node_fields=None,
-                    split_decoupled: bool = True):
+                    split_decoupled: bool = True, smoother_degree: int = 1):
     """Device version of ``amg.build_hierarchy`` (same arguments, same kind of result; ``node_fields``: aggregation on the node
     graph of the first field, shared by all fields; ``split_decoupled``: unknowns without off-diagonal entries are solved by the
-    smoother and not carried to coarser levels -- see amg.build_hierarchy)."""
+    smoother and not carried to coarser levels, only with a degree-1 smoother -- see amg.build_hierarchy)."""
+    split_decoupled = bool(split_decoupled) and int(smoother_degree) == 1
     A = _from_scipy(P, device)
     A_host = sp.csr_matrix(P, dtype=np.float64)
     A_host.sort_indices()
@@ -232,7 +233,7 @@ def build_hierarchy(P, theta: float = 0.08, max_levels: int = 12, coarse_size: i
                     Af = _from_coo(torch.div(r_[mf], stride, rounding_mode="floor"), torch.div(c_[mf], stride, rounding_mode="floor"), v_[mf], (nn, nn))
                     degf = torch.bincount(torch.div(_strength(Af, th), nn, rounding_mode="floor"), minlength=nn)
                     if bool(((degf == 0) & (deg0 > 0)).any()) or bool(((diag[f::stride] <= 0) & (diag[f0::stride] > 0)).any()):
-                        return build_hierarchy(P, theta, max_levels, coarse_size, agg_distance, device, None, split_decoupled)
+                        return build_hierarchy(P, theta, max_levels, coarse_size, agg_distance, device, None, split_decoupled, smoother_degree)
             act_n = active[f0::stride]
             ian = torch.nonzero(act_n).squeeze(1)
             n_act_n = int(ian.numel())

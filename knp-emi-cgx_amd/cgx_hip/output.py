@@ -258,11 +258,25 @@ class RunOutput:
         X["steps"].append((float(p.t.value), names))
         self._write_solution_xml()
 
+    _XML_TAIL = ['    </Grid>', '  </Domain>', '</Xdmf>', '']
+
     def _write_solution_xml(self):
+        """solution.xdmf is always a complete document: the text of the steps not yet written is put where the closing tags of
+        the previous version began, followed by the closing tags again -- O(steps) text in total (regenerating the
+        whole file at every save was O(steps^2))."""
         X = self.xdmf
         nc, npt, dim = X["dims"]
-        body = list(X["head"]) + ['    <Grid Name="solution" GridType="Collection" CollectionType="Temporal">']
-        for k, (t, names) in enumerate(X["steps"]):
+        if "xml_pos" not in X:
+            head = self._xdmf_text(list(X["head"]) + ['    <Grid Name="solution" GridType="Collection" CollectionType="Temporal">'])
+            head = head[:head.index("  </Domain>")]
+            with open(X["xname"], "w") as f:
+                f.write(head)
+                X["xml_pos"] = f.tell()
+                f.write("\n".join(self._XML_TAIL))
+            X["xml_steps"] = 0
+        body = []
+        for k in range(X["xml_steps"], len(X["steps"])):
+            t, names = X["steps"][k]
             body += [f'      <Grid Name="step_{k}" GridType="Uniform">', f'        <Time Value="{t!r}" />']
             body += ["  " + ln for ln in self._mesh_items(X["h5"], nc, npt, dim)]
             for nm in names:
@@ -270,9 +284,15 @@ class RunOutput:
                          f'          <DataItem Dimensions="{npt} 1" NumberType="Float" Precision="8" Format="HDF">{X["h5"]}:/Function/{nm}/{k}</DataItem>',
                          f'        </Attribute>']
             body += ['      </Grid>']
-        body += ['    </Grid>']
-        with open(X["xname"], "w") as f:
-            f.write(self._xdmf_text(body))
+        if not body:
+            return
+        with open(X["xname"], "r+") as f:
+            f.seek(X["xml_pos"])
+            f.write("\n".join(body) + "\n")
+            X["xml_pos"] = f.tell()
+            f.write("\n".join(self._XML_TAIL))
+            f.truncate()
+        X["xml_steps"] = len(X["steps"])
 
     def close_xdmf(self):
         if self.xdmf is not None:

@@ -173,7 +173,7 @@ class SolverKNPEMI:
                 return
             P = P[:, :be.n_dof_owned].tocsr()          # per-rank block (block-Jacobi across GPUs)
             host_build = lambda M, nf=None: amg.build_hierarchy(M, theta=self.amg_theta, coarse_size=self.amg_coarse_size, node_fields=nf,
-                                                                split_decoupled=self.amg_split_decoupled)
+                                                                split_decoupled=self.amg_split_decoupled, smoother_degree=self.amg_cheby_degree)
             if str(self.amg_setup) == "gpu":
                 from . import amg_gpu
 
@@ -182,7 +182,7 @@ class SolverKNPEMI:
                     # products are not usable on this installation, build the same hierarchy with SciPy
                     try:
                         return amg_gpu.build_hierarchy(M, theta=self.amg_theta, coarse_size=self.amg_coarse_size, device=be.device, node_fields=nf,
-                                                       split_decoupled=self.amg_split_decoupled)
+                                                       split_decoupled=self.amg_split_decoupled, smoother_degree=self.amg_cheby_degree)
                     except (RuntimeError, NotImplementedError) as exc:
                         self.print(f"device-side AMG setup unavailable ({type(exc).__name__}: {exc}); using the host setup")
                         return host_build(M, nf)
@@ -327,6 +327,18 @@ class SolverKNPEMI:
             self._sync()
             setup_timer += self.comm.allreduce_max(time.perf_counter() - tic)
 
+        try:
+            self._time_loop(setup_timer)
+        finally:
+            # a run that raises (strict non-convergence, NaN, a failed exchange) or is interrupted must still leave a readable
+            # solution.h5: its metadata and superblock are written at close (reference: XDMFFile flushes per write)
+            if self.save_xdmfs and getattr(self, "output", None) is not None:
+                self.output.close_xdmf()
+
+    def _time_loop(self, setup_timer):
+        p = self.problem
+        t, dt = p.t, p.dt
+        be = self.backend
         for i in range(1, self.time_steps + 1):
             p.t.value += float(dt.value)
             self.print("\nTime step ", i)

@@ -2564,6 +2564,7 @@ int knp_matrix_max_abs(knp_ctx* ctx, double* out) {
     CHECK_CTX(ctx);
     if (!out) return KNP_E_ARG;
     if (!ctx->have_A) { ctx->err = "matrix not assembled"; return KNP_E_STATE; }
+    side_discard(ctx);   // d_partial is also the side stream's reduction scratch (knp_gmres_prepare)
     const double* arr[3] = {ctx->d_at, ctx->d_ac, ctx->d_ax};
     const int64_t len[3] = {4 * ctx->n_pairs, 6 * ctx->n_pairs, 8 * ctx->n_gp};
     std::vector<double> h(3 * RED_BLOCKS, 0.0);
@@ -2947,6 +2948,20 @@ static int64_t global_phi_count(knp_ctx* ctx, int* rc) {
     if (hipMemcpy(ctx->h_red + 63, ctx->d_red + 63, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { *rc = KNP_E_HIP; return 0; }
     ctx->phi_count_cached = (int64_t)llround(ctx->h_red[63]);
     return ctx->phi_count_cached;
+}
+
+// SUM over the ranks of a few host values (setup-time decisions that every rank must take identically); slots 104.. of d_red.
+// Collective on distributed contexts, the identity on one GPU.
+static int global_sum_small(knp_ctx* ctx, double* vals, int n) {
+    constexpr int SLOT0 = 104;
+    if (n < 0 || SLOT0 + n > RED_SLOTS) { ctx->err = "global_sum_small: too many values"; return KNP_E_ARG; }
+    if (n == 0 || !(ctx->allreduce || ctx->p2p_red >= 0)) return KNP_OK;
+    HIPCHK(hipMemcpyAsync(ctx->d_red + SLOT0, vals, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    KCHK(allreduce_slots(ctx, SLOT0, n));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(vals, ctx->d_red + SLOT0, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    return ctx->p2p ? knp_p2p_check(ctx) : KNP_OK;
 }
 
 int knp_set_nullspace(knp_ctx* ctx, int32_t on) {
@@ -3757,15 +3772,24 @@ int knp_pc_setup(knp_ctx* ctx, int32_t kind) {
                       L0.S_rows == L0.n && have_pt) ? 1 : 0;
         // the levels below it likewise (distributed levels and the replicated tail): At = c A Dinv for the down-leg, S for the up-leg
         const bool used = (kind == KNP_PC_AMG && h == 0) || ((kind == KNP_PC_AMG_BT || kind == KNP_PC_AMG_LT) && h < 2);
+        // Eligibility is decided GLOBALLY: build_level_scaled and the fused leg exchange a different number of halos than the
+        // unfused one, so a rank that owns nothing on a distributed level must still take the decision of its peers.
+        // Every rank contributes "1 = my part of this level cannot run fused"; the level is fused where the sum is zero.
+        double veto[KNP_MAX_AMG_LEVELS] = {0};
+        const bool lvl_off = getenv("KNP_FUSED_LEVELS") && atoi(getenv("KNP_FUSED_LEVELS")) == 0;
         for (int l = 1; l < H.levels - 1; ++l) {
             KnpAmgLevel& L = H.lv[l];
             dev_free(L.At_v); dev_free(L.At_vf);
             L.lfused = 0;
-            const bool lvl_off = getenv("KNP_FUSED_LEVELS") && atoi(getenv("KNP_FUSED_LEVELS")) == 0;
-            if (!used || off || lvl_off || H.fused || H.cheby != 1 || H.pre != 1 || H.post != 1 || !L.S_rp || L.S_rows != L.n || L.S_n_act > 0 ||
-                L.n_coarse <= 0 || L.A_nnz <= 0 || !L.inv_diag) continue;
+            const bool empty_here = L.dist && L.n == 0;      // owns no rows of a distributed level: follows its peers
+            const bool local_ok = !(!L.S_rp || L.S_rows != L.n || L.S_n_act > 0 || L.n_coarse <= 0 || L.A_nnz <= 0 || !L.inv_diag);
+            veto[l] = (!used || off || lvl_off || H.fused || H.cheby != 1 || H.pre != 1 || H.post != 1 || !(local_ok || empty_here)) ? 1.0 : 0.0;
+        }
+        if (used && H.levels > 2) KCHK(global_sum_small(ctx, veto + 1, H.levels - 2));
+        for (int l = 1; l < H.levels - 1; ++l) {
+            if (veto[l] != 0.0) continue;
             KCHK(build_level_scaled(ctx, h, l));
-            L.lfused = 1;
+            H.lv[l].lfused = 1;
         }
     }
     if (kind == KNP_PC_VBJACOBI && ctx->have_A) {
@@ -3999,7 +4023,14 @@ int knp_gmres_solve(knp_ctx* ctx, const double* b, double* x, double rtol, doubl
     CHECK_CTX(ctx);
     if (!b || !x || !its || !rnorm || !reason) return KNP_E_ARG;
     if (!ctx->have_A) { ctx->err = "matrix not assembled"; return KNP_E_STATE; }
-    if (restart < 1 || restart > RED_SLOTS - 8 || max_it < 0) { ctx->err = "restart must be in [1,56]"; return KNP_E_ARG; }
+    // slot layout of d_red: 0 .. restart+1 = the Gram-Schmidt coefficients, the gauge coefficient and w.w of one iteration (nred = j + 2 + ns
+    // <= restart + 2 values), GM_EXPL = 57 the explicit norm of the cancellation fallback, 58..63 norms / flags, 64.. deflation, 100.. the mirror
+    constexpr int GM_RES = 100, GM_EXPL = 57, GM_MAX_RESTART = GM_EXPL - 2;
+    static_assert(GM_RES + 2 <= RED_SLOTS && DEFL_SLOT0 + DEFL_MAX <= GM_RES, "reduction slot layout");
+    if (restart < 1 || restart > GM_MAX_RESTART || max_it < 0) {
+        ctx->err = "restart must be in [1," + std::to_string(GM_MAX_RESTART) + "] and max_it >= 0";
+        return KNP_E_ARG;
+    }
     KCHK(ensure_work(ctx, restart));
     prof_collect_ready(ctx);
     const int n = ctx->n_dof_owned;
@@ -4020,7 +4051,6 @@ int knp_gmres_solve(knp_ctx* ctx, const double* b, double* x, double rtol, doubl
     }
     double* gm = ctx->d_gm;
     // residual estimate and flag of the last k_givens: pinned mirror (slots GM_RES, GM_RES+1) + sequence word, or a copy on the hook path
-    constexpr int GM_RES = 100, GM_EXPL = 57;
     auto read_state = [&](double& res_out, int& flag_out) -> int {
         ++ctx->n_readback;
         if (ctx->mirror() && ctx->h_seq_dev) {

@@ -273,6 +273,9 @@ def test_abi_argument_validation():
     be.assemble_matrix()
     rc = lib.knp_gmres_solve(be.ctx, be.b.data_ptr(), be.x.data_ptr(), 1e-9, 1e-50, 10, 500, C.byref(its), C.byref(rn), C.byref(reason))
     assert rc == -1
+    # ... the slot layout carries restart + 2 values per reduction in 57 slots: 55 is the largest legal restart
+    rc = lib.knp_gmres_solve(be.ctx, be.b.data_ptr(), be.x.data_ptr(), 1e-9, 1e-50, 10, 56, C.byref(its), C.byref(rn), C.byref(reason))
+    assert rc == -1 and b"[1,55]" in lib.knp_last_error(be.ctx)
     # Dirichlet dof out of range
     bad = (C.c_int32 * 1)(10 ** 8)
     assert lib.knp_set_dirichlet(be.ctx, 1, bad) == -1

@@ -59,3 +59,44 @@ def test_libhdf5_reads_the_writers_files(tmp_path):
         pytest.skip("conda interpreter without h5py")
     assert r.returncode == 0, r.stderr[-800:]
     assert r.stdout.split()[:3] == ["OK", str(len(data)), "300"], r.stdout
+
+
+def test_solution_xdmf_is_a_complete_document_after_every_save(tmp_path):
+    """solution.xdmf is appended to (O(steps) text) and parses as XML after every save; a run that stops early and closes
+    the writer in its ``finally`` leaves a readable .h5 with the steps written so far."""
+    import xml.etree.ElementTree as ET
+    from types import SimpleNamespace as NS
+    from cgx_hip import hdf5_min
+    from cgx_hip.output import RunOutput
+
+    class F:
+        def __init__(self, name, n):
+            self.name, self.v = name, np.zeros(n)
+
+        def numpy(self):
+            return self.v
+    n_pts = 9
+    coords = np.random.default_rng(0).random((n_pts, 2))
+    cells = np.array([[0, 1, 2], [2, 3, 4], [4, 5, 6], [6, 7, 8]])
+    p = NS(local_mesh=NS(coords=coords, cells=cells, cell_tags=np.array([1, 1, 2, 2])), comm=NS(rank=0, size=1), num_variables=2,
+           wh=[[F("Na_i", n_pts), F("phi_i", n_pts)], [F("Na_e", n_pts), F("phi_e", n_pts)]], t=NS(value=0.0), print=lambda *a, **k: None)
+    out = RunOutput.__new__(RunOutput)
+    out.p, out.prefix, out.xdmf = p, str(tmp_path) + os.sep, None
+    out.init_xdmf_savefile()                              # step 0
+    sizes = []
+    for k in range(1, 6):
+        p.t.value = 0.1 * k
+        for side in p.wh:
+            for f in side:
+                f.v[:] = k
+        out.save_xdmf()
+        root = ET.parse(tmp_path / "solution.xdmf").getroot()
+        steps = root.findall(".//Grid[@CollectionType='Temporal']/Grid")
+        assert len(steps) == k + 1 and float(steps[-1].find("Time").get("Value")) == pytest.approx(0.1 * k)
+        sizes.append(os.path.getsize(tmp_path / "solution.xdmf"))
+    assert len(set(np.diff(sizes))) <= 2                  # constant growth per step (the time value's repr may vary by a character or two)
+    out.close_xdmf()                                      # what SolverKNPEMI.solve does in its finally block
+    out.close_xdmf()                                      # idempotent
+    f = hdf5_min.Hdf5File(tmp_path / "solution.h5")
+    assert len(f.keys("/Function/phi_i")) == 6 and np.all(f.read("/Function/phi_e/5") == 5.0)
+    assert len(ET.parse(tmp_path / "solution.xdmf").getroot().findall(".//Grid[@CollectionType='Temporal']/Grid")) == 6
