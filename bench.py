@@ -39,6 +39,12 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MIN_TIMED_S = 0.5         # repeat the K-step bracket until this much has been timed
 MAX_REPS = 40
 PARITY_TOL = 1e-6         # north_star: potentials match the reference solve to rtol 1e-6
+# True residual of the sampled step with the ORACLE's A and b.  The solve stops on the PRECONDITIONED residual at rtol 1e-9 (reference:
+# ksp_norm_type preconditioned), which leaves 2e-6 of ||b|| overall on 512^2 (measured; the oracle's own GMRES leaves the same) and
+# 1e-11 normwise backward error ||r|| / (|| |A||x| || + ||b||) in every field block -- the phi-rows have an almost empty right-hand side
+# (membrane terms only), so only the backward error is a meaningful gate there.
+TRUE_RES_TOL = 1e-5
+BACKWARD_TOL = 1e-9
 
 
 def parse():
@@ -54,6 +60,8 @@ def parse():
     ap.add_argument("--models", type=str, default="ci", help="ci (HH+ATP+cotransporters) | passive")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-parity-lu", action="store_true", help="parity leg: true residual only, skip the oracle's sparse direct solve "
+                    "(nested-dissection LU of the sampled step: ~1.5 min and 6 GB at 512^2; 2D workloads up to 1.2 M unknowns only)")
     ap.add_argument("--large", type=str, default="cube136", help="out-of-cache workload of the roofline_large block ('' or 'none' disables)")
     ap.add_argument("--large-steps", type=int, default=4)
     ap.add_argument("--no-repeat", action="store_true", help="time the K steps once, whatever their duration")
@@ -139,40 +147,22 @@ def build_case(workload, args, world, rank, steps_total):
 
 
 class Stepper:
-    """The reference loop body (KNPEMIx_solver.py:365-468), one call per timestep."""
+    """Drives the drop-in entry point itself: ``SolverKNPEMI.prepare()`` once, then ``SolverKNPEMI.step(i)`` per timestep -- the very
+    loop body ``SolverKNPEMI.solve()`` runs (reference KNPEMIx_solver.py:365-468); nothing is re-implemented here."""
 
     def __init__(self, case):
-        from cgx_hip import _lib
-        from cgx_hip.ionic_models import HodgkinHuxley
-        self.HH = HodgkinHuxley
         self.solver, self.problem = case["solver"], case["problem"]
-        s = self.solver
-        s.setup_solver()
-        self.be = s.backend
-        if s._pc_kind in (_lib.PC_AMG, _lib.PC_AMG_BT):
-            self.problem.setup_preconditioner(s.use_block_Jacobi)
-            s.assemble_preconditioner()
-        self.be.pc_setup(s._pc_kind)
+        t0 = time.perf_counter()
+        self.solver.prepare()
+        self.be = self.solver.backend
+        self.prepare_s = time.perf_counter() - t0
         self.i = 0
 
     def step(self):
         self.i += 1
-        p, s, be = self.problem, self.solver, self.be
-        p.t.value += float(p.dt.value)
-        if p.gating_variables:
-            for model in p.ionic_models:
-                if isinstance(model, self.HH):
-                    model.update_t_mod()
-                    model.update_gating_variables()
-        be.assemble_rhs()
-        if self.i > 1:
-            be.gmres_prepare()          # ||B b|| on the side stream while the matrix is assembled (as SolverKNPEMI.assemble does)
-        be.assemble_matrix()
-        if self.i == 1:
-            s.create_and_set_nullspace()
-        its, rnorm, reason = be.gmres(s._rtol, 1e-50, s.ksp_max_it, s.gmres_restart)
-        be.unpack()
-        return its, reason
+        s = self.solver
+        s.step(self.i)
+        return s.iterations[-1], s.reasons[-1]
 
 
 def spmv_bytes(be):
@@ -232,11 +222,20 @@ def timed_run(case, args, world, dist, torch, steps, warmup, snapshot_at=None, a
         torch.cuda.synchronize()
 
     snap = None
+    state_before = None
+    t_first = None
     for _ in range(warmup):
+        if snapshot_at is not None and st.i == snapshot_at - 1 and st.i >= 1:
+            state_before = problem_state(case["problem"])      # the state the snapshot step starts from (single-step checker)
+        t0 = time.perf_counter()
         st.step()
+        if st.i == 1:
+            torch.cuda.synchronize()
+            t_first = time.perf_counter() - t0
         if snapshot_at is not None and st.i == snapshot_at:
             ni, ne = solver.potential_norms()
-            snap = {"step": st.i, "phi_i": ni, "phi_e": ne, "phi_m": case["problem"].phi_m_prev.numpy().copy()}
+            snap = {"step": st.i, "phi_i": ni, "phi_e": ne, "phi_m": case["problem"].phi_m_prev.numpy().copy(),
+                    "x": be.x.cpu().numpy().copy(), "state_before": state_before}
     be.profile_reset()
     be.profile_enable(int(os.environ.get("KNP_BENCH_PROFILE_MASK", profile_mask)))      # (developer knob: 0 = no events at all)
     reps, its_all, reasons = [], [], []
@@ -263,7 +262,22 @@ def timed_run(case, args, world, dist, torch, steps, warmup, snapshot_at=None, a
     be.profile_enable(0)
     srt = sorted(reps)
     med = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
-    return {"stepper": st, "elapsed": med, "reps": reps, "its": its_all, "reasons": reasons, "prof": prof, "stats": stats, "snap": snap}
+    setup = dict(solver.setup_breakdown)
+    setup["amg_hierarchy_s"] = float(getattr(solver, "amg_setup_time", 0.0))      # part of preconditioner_setup_s
+    setup["first_step_s"] = t_first
+    setup["total_before_first_step_s"] = st.prepare_s
+    return {"stepper": st, "elapsed": med, "reps": reps, "its": its_all, "reasons": reasons, "prof": prof, "stats": stats, "snap": snap,
+            "setup_s": setup}
+
+
+def problem_state(p):
+    """host copy of the time-dependent state (what oracle.load_state takes): concentrations, potentials, phi_m, gating, t"""
+    st = {"k_i": [p.wh[0][j].numpy().copy() for j in range(3)], "k_e": [p.wh[1][j].numpy().copy() for j in range(3)],
+          "phi_i": p.wh[0][3].numpy().copy(), "phi_e": p.wh[1][3].numpy().copy(), "phi_m": p.phi_m_prev.numpy().copy(), "t": float(p.t.value)}
+    for nm in ("n", "m", "h"):
+        f = getattr(p, nm, None)
+        st[nm] = f.numpy().copy() if f is not None and hasattr(f, "numpy") else None
+    return st
 
 
 def main_case(args, world, rank, dist, torch):
@@ -302,6 +316,8 @@ def main_case(args, world, rank, dist, torch):
         "roofline": roof,
         "cpu_baseline": None, "parity": None, "roofline_large": None,
         "kernel_classes_ms": {k: {"ms": v[0], "launches": v[1]} for k, v in run["prof"].items()} if args.profile_all else None,
+        "setup_s": run["setup_s"],
+        "entry_point": "SolverKNPEMI.prepare() + SolverKNPEMI.step(i): the loop body of SolverKNPEMI.solve()",
     }
     fail = None
     if not out["config"]["converged_all"]:
@@ -392,7 +408,7 @@ def large_block(args, torch, dist):
            "kernel_classes_ms_per_step": {k: {"ms": v[0] / n_steps, "launches": v[1] / n_steps} for k, v in run["prof"].items()},
            "note": "kernel classes are timed with HIP event pairs around each group of launches (serialises nothing, but adds event records: "
                    "ms_per_step here is a few percent above an unprofiled run)",
-           "wall_s_incl_setup": None}
+           "setup_s": run["setup_s"], "wall_s_incl_setup": None}
     blk["wall_s_incl_setup"] = time.perf_counter() - t0
     return blk
 
@@ -456,12 +472,34 @@ def cpu_baseline(case, args, solver, snap):
     par = None
     if snap is not None and osnap:
         s = float(np.abs(osnap["phi_m"]).max())
+        # (1) same-algorithm trajectory: the oracle's GMRES with the same preconditioner construction, steps 1..snap
         par = {"step": snap["step"], "checker": "oracle GMRES with the same preconditioner algorithm, same rtol",
                "rel_err_phi_i_L2": abs(snap["phi_i"] - osnap["phi_i"]) / osnap["phi_i"],
                "rel_err_phi_e_L2": abs(snap["phi_e"] - osnap["phi_e"]) / osnap["phi_e"],
+               "abs_err_phi_e_L2_over_phi_i_L2": abs(snap["phi_e"] - osnap["phi_e"]) / osnap["phi_i"],
                "rel_err_phi_m_max": float(np.abs(snap["phi_m"] - osnap["phi_m"]).max()) / s,
-               "tol": PARITY_TOL}
-        par["ok"] = bool(par["rel_err_phi_i_L2"] <= PARITY_TOL and par["rel_err_phi_m_max"] <= PARITY_TOL)
+               "tol": PARITY_TOL,
+               "phi_e_statement": "||phi_e||_L2 is matched to tol * ||phi_i||_L2 (1e-6 of the potential scale): phi_e is 100-2000x smaller than "
+                                  "phi_i here, so the truncation of an rtol-%g solve is amplified in its own relative error (reported, not gated)" % rtol}
+        ok = par["rel_err_phi_i_L2"] <= PARITY_TOL and par["rel_err_phi_m_max"] <= PARITY_TOL and par["abs_err_phi_e_L2_over_phi_i_L2"] <= PARITY_TOL
+        # (2) preconditioner-independent: the oracle redoes the sampled step from the GPU's own state before it -- its A and b applied
+        # to the GPU's solution (true residual per field block) and, in 2D, its sparse direct solve of that step
+        if snap.get("state_before") is not None:
+            want_lu = (not args.no_parity_lu) and kind == "square" and o.n_dof <= 1_200_000
+            chk = K.single_step_check(mk(N, models=mdl), snap["state_before"], snap["x"], lu=want_lu)
+            par["true_residual"] = {"rel_to_b": chk["rel_residual"], "max_block_backward_error": chk["max_backward"],
+                                    "blocks": chk["blocks"], "gauge_drift": chk["gauge_drift"], "tol_rel_to_b": TRUE_RES_TOL,
+                                    "tol_backward": BACKWARD_TOL,
+                                    "what": "||b - A x_gpu|| with the ORACLE's A, b of the sampled step (assembled from the GPU's previous state)"}
+            ok = ok and chk["rel_residual"] <= TRUE_RES_TOL and chk["max_backward"] <= BACKWARD_TOL
+            if want_lu:
+                par["direct_solve"] = {"checker": "oracle sparse LU (nested dissection) of the same step, same gauge", "lu_s": chk["lu_s"],
+                                       "field_max_rel_diff": chk["lu_field_diff"], "rel_err_phi_i_L2": chk["rel_err_phi_i_L2"],
+                                       "rel_err_phi_e_L2": chk["rel_err_phi_e_L2"], "abs_err_phi_e_L2_over_phi_i_L2": chk["abs_err_phi_e_over_phi_i"],
+                                       "rel_err_phi_m_max": chk["rel_err_phi_m_max"], "lu_rel_residual": chk["lu_rel_residual"]}
+                ok = ok and chk["rel_err_phi_i_L2"] <= PARITY_TOL and chk["rel_err_phi_m_max"] <= PARITY_TOL and \
+                    chk["abs_err_phi_e_over_phi_i"] <= PARITY_TOL and max(chk["lu_field_diff"]) <= PARITY_TOL
+        par["ok"] = bool(ok)
     return cpu, par
 
 

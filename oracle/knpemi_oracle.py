@@ -672,6 +672,38 @@ class OracleKNPEMI:
     def potential_norms(self):
         return self.l2_norm(self.phi[0], 0), self.l2_norm(self.phi[1], 1)
 
+    def node_coords(self):
+        """coordinates of the nodes (vertex, side) in node order: input of the nested-dissection ordering"""
+        L = self.lay
+        X = np.zeros((self.n_dof // 4, self.dim))
+        for nodes in (L.node_i, L.node_e):
+            v = np.nonzero(nodes >= 0)[0]
+            X[nodes[v]] = self.coords[v]
+        return X
+
+    def load_state(self, st):
+        """Set the time-dependent state from a snapshot {k_i[3], k_e[3], phi_i, phi_e, phi_m, n, m, h, t}: lets a checker redo ONE
+        implicit step from the state another implementation was in (single-step parity, independent of the trajectory so far)."""
+        for j in range(3):
+            self.k[0][j] = np.array(st["k_i"][j], dtype=np.float64)
+            self.k[1][j] = np.array(st["k_e"][j], dtype=np.float64)
+        self.phi = [np.array(st["phi_i"], dtype=np.float64), np.array(st["phi_e"], dtype=np.float64)]
+        self.phi_m = np.array(st["phi_m"], dtype=np.float64)
+        for nm in ("n", "m", "h"):
+            if st.get(nm) is not None:
+                setattr(self, nm, np.array(st[nm], dtype=np.float64))
+        self.t = float(st["t"])
+
+    def step_system(self):
+        """Advance t, update the gating variables, assemble (A, b) of the next implicit step (KNPEMIx_solver.py:368,395-403,
+        104-116) WITHOUT solving it; b is not projected (only step 1 projects, :333)."""
+        self.t += self.p.dt
+        for mdl in self.models:
+            if mdl.kind == "hh":
+                self.update_t_mod()
+                self.update_gating(mdl)
+        return self.assemble_A().tocsr(), self.assemble_b()
+
     # ---- time loop (KNPEMIx_solver.py:337-468)
     # class defaults of the reference's constants (KNPEMIx_problem.py:941-951)
     REF_DEFAULT_KI, REF_DEFAULT_KE, REF_DEFAULT_PHI_M = (10.0, 130.0, 5.0), (145.0, 3.0, 134.0), -0.070
@@ -791,6 +823,126 @@ def solve_lu_gauge(A, b, ns, gauge_value):
     rhs = np.concatenate([b, [gauge_value]])
     sol = spla.splu(K).solve(rhs)
     return sol[:n]
+
+
+def nested_dissection_order(A, block=4, coords=None, leaf=96):
+    """Fill-reducing ordering for the sparse LU of the block system: recursive coordinate bisection of the NODE graph (``block``
+    unknowns per node) with vertex separators ordered last.  SuperLU's COLAMD needs 107 M factor entries and 16 s for the 128^2
+    square, this ordering 20 M and 1.5 s; it is what makes one direct solve of the 512^2 benchmark case (the check the
+    reference's own direct-solver test performs, tests/KNPEMI/electric_potential_norms_direct_solver.py:55-68 with MUMPS) affordable
+    on one core.  ``coords`` [n_nodes, dim]; without them the node index is used as a 1-D coordinate (band-like splitting).
+    Returns a permutation of the unknowns."""
+    n = A.shape[0]
+    nn = n // block
+    assert nn * block == n
+    coo = A.tocoo()
+    G = sp.csr_matrix((np.ones(coo.nnz, dtype=np.int8), (coo.row // block, coo.col // block)), shape=(nn, nn))
+    G = ((G + G.T) > 0).astype(np.int32).tocsr()
+    X = np.arange(nn, dtype=np.float64)[:, None] if coords is None else np.asarray(coords, dtype=np.float64)
+    mark = np.zeros(nn, dtype=np.int32)
+    pieces = []
+
+    def rec(idx):
+        if idx.size <= leaf:
+            pieces.append(idx)
+            return
+        ext = X[idx].max(axis=0) - X[idx].min(axis=0)
+        c = X[idx, int(np.argmax(ext))]
+        med = np.partition(c, idx.size // 2)[idx.size // 2]
+        lo = c < med
+        if not lo.any() or lo.all():                  # many equal coordinates: split by position
+            lo = np.zeros(idx.size, dtype=bool)
+            lo[np.argsort(c, kind="stable")[:idx.size // 2]] = True
+        left, right = idx[lo], idx[~lo]
+        mark[right] = 1
+        touch = (G[left] @ mark) > 0                  # left nodes with a neighbour on the right: the separator
+        mark[right] = 0
+        rec(left[~touch])
+        rec(right)
+        pieces.append(left[touch])
+    import sys as _sys
+    _sys.setrecursionlimit(max(_sys.getrecursionlimit(), 10000))
+    rec(np.arange(nn))
+    order = np.concatenate(pieces)
+    assert order.size == nn
+    return (block * order[:, None] + np.arange(block)[None, :]).ravel()
+
+
+def solve_lu_gauge_nd(A, b, ns, gauge_value, node_coords=None, block=4):
+    """``solve_lu_gauge`` with the nested-dissection ordering above (same bordered system, the gauge row/column last)."""
+    n = A.shape[0]
+    perm = np.concatenate([nested_dissection_order(A, block, node_coords), [n]])
+    K = sp.bmat([[A, sp.csr_matrix(ns[:, None])], [sp.csr_matrix(ns[None, :]), None]], format="csr")
+    Kp = K[perm][:, perm].tocsc()
+    rhs = np.concatenate([b, [gauge_value]])
+    lu = spla.splu(Kp, permc_spec="NATURAL", diag_pivot_thresh=0.0)
+    sol = np.empty(n + 1)
+    sol[perm] = lu.solve(rhs[perm])
+    # one step of iterative refinement (static pivoting on the diagonal): keeps the residual at the level of partial pivoting
+    r = rhs - K @ sol
+    d = np.empty(n + 1)
+    d[perm] = lu.solve(r[perm])
+    return (sol + d)[:n]
+
+
+def single_step_check(o, state, x_new, lu=True, blocks=True):
+    """Preconditioner-independent check of ONE implicit step of another implementation (the HIP path): the oracle is put into
+    the state that implementation was in BEFORE the step (``state``, see OracleKNPEMI.load_state), assembles its own A and b of
+    the step, and measures
+      * the TRUE residual of the candidate solution ``x_new``: ||b - A x|| / ||b|| overall and per field block of the reference's
+        block vector [k_i^1..3, phi_i | k_e^1..3, phi_e] (KNPEMIx_problem.py:34-48), plus the normwise backward error
+        ||r|| / (|| |A| |x| || + ||b||) per block (the phi-rows have a tiny right-hand side: only membrane terms);
+      * with ``lu``: the difference to the oracle's own sparse direct solve of the same system in the same gauge (what the
+        reference's direct-solver test pins, tests/KNPEMI/electric_potential_norms_direct_solver.py:55-68): per field max-norm
+        relative differences, the L2 norms of both potentials, phi_m on the membrane.
+    Nothing here depends on the candidate's preconditioner, Krylov method or iteration history.  Leaves ``o`` advanced by the
+    step (with the direct solution when ``lu``, else with x_new)."""
+    import time as _time
+    o.load_state(state)
+    ns = o.nullspace()
+    gauge = float(ns @ o.pack())
+    t0 = _time.perf_counter()
+    A, b = o.step_system()
+    t_asm = _time.perf_counter() - t0
+    x = np.asarray(x_new, dtype=np.float64)
+    r = b - A @ x
+    out = {"assemble_s": t_asm, "n_dof": int(o.n_dof), "rel_residual": float(np.linalg.norm(r) / np.linalg.norm(b)),
+           "gauge_drift": float(abs(ns @ x - gauge) / max(abs(gauge), 1e-300))}
+    if blocks:
+        Aabs = abs(A)
+        ax = Aabs @ np.abs(x)
+        side = np.zeros(o.n_dof // 4, dtype=np.int8)
+        side[o.lay.node_e[o.lay.node_e >= 0]] = 1
+        names = ("Na", "K", "Cl", "phi")
+        blk = {}
+        for sd, sn in ((0, "i"), (1, "e")):
+            nodes = np.nonzero(side == sd)[0]
+            for f in range(4):
+                d = 4 * nodes + f
+                nb = float(np.linalg.norm(b[d]))
+                blk[f"{names[f]}_{sn}"] = {"rel_to_b": float(np.linalg.norm(r[d]) / nb) if nb > 0 else None,
+                                           "backward": float(np.linalg.norm(r[d]) / (np.linalg.norm(ax[d]) + nb))}
+        out["blocks"] = blk
+        out["max_backward"] = max(v["backward"] for v in blk.values())
+    if lu:
+        t0 = _time.perf_counter()
+        xd = solve_lu_gauge_nd(A, b, ns, gauge, o.node_coords())
+        out["lu_s"] = _time.perf_counter() - t0
+        out["lu_rel_residual"] = float(np.linalg.norm(b - A @ xd) / np.linalg.norm(b))
+        out["lu_field_diff"] = [float(np.abs(x[f::4] - xd[f::4]).max() / np.abs(xd[f::4]).max()) for f in range(4)]
+        o.unpack(x)
+        ci, ce = o.potential_norms()
+        pm_c = o.phi_m.copy()
+        o.unpack(xd)
+        di, de = o.potential_norms()
+        gam = (o.lay.node_i >= 0) & (o.lay.node_e >= 0)
+        out.update(phi_i_L2=ci, phi_e_L2=ce, lu_phi_i_L2=di, lu_phi_e_L2=de,
+                   rel_err_phi_i_L2=abs(ci - di) / di, rel_err_phi_e_L2=abs(ce - de) / de,
+                   abs_err_phi_e_over_phi_i=abs(ce - de) / di,
+                   rel_err_phi_m_max=float(np.abs(pm_c[gam] - o.phi_m[gam]).max() / np.abs(o.phi_m[gam]).max()))
+    else:
+        o.unpack(x)
+    return out
 
 
 def solve_lu_pin(A, b, pin):

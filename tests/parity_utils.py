@@ -105,3 +105,38 @@ def oracle_gmres_same_algorithm(kind, N, steps, pc, rtol, solver, models="ci"):
         return K.pc_amg_vcycle(h.levels, h.coarse_inv, pre, post, deg, fused=fused)
     _, its = o.run(steps, solver="gmres", pc=fac, rtol=rtol)
     return o, its
+
+
+def snapshot_state(problem):
+    """The time-dependent state of the native problem as host arrays (input of ``OracleKNPEMI.load_state``): the checker redoes
+    ONE step from exactly the state the GPU path was in, so the comparison does not depend on the trajectory before it."""
+    p = problem
+    st = {"k_i": [p.wh[0][j].numpy().copy() for j in range(3)], "k_e": [p.wh[1][j].numpy().copy() for j in range(3)],
+          "phi_i": p.wh[0][3].numpy().copy(), "phi_e": p.wh[1][3].numpy().copy(), "phi_m": p.phi_m_prev.numpy().copy(),
+          "t": float(p.t.value)}
+    for nm in ("n", "m", "h"):
+        f = getattr(p, nm, None)
+        st[nm] = f.numpy().copy() if f is not None and hasattr(f, "numpy") else None
+    return st
+
+
+def run_with_snapshots(solver, steps):
+    """``SolverKNPEMI.solve()`` -- the reference's loop, nothing changed -- recording after every step in ``steps`` the state
+    (``snapshot_state``), the solution vector, the potential norms and phi_m: ``snaps[i]``."""
+    s, p = solver, solver.problem
+    snaps = {}
+    s.setup_solver()
+    be = s.backend
+    orig_unpack = be.unpack
+    count = {"i": 0}
+
+    def unpack():
+        orig_unpack()
+        count["i"] += 1
+        if count["i"] in steps:
+            snaps[count["i"]] = {"state": snapshot_state(p), "norms": s.potential_norms(), "phi_m": p.phi_m_prev.numpy().copy(),
+                                 "x": be.x.cpu().numpy().copy()}
+    be.unpack = unpack
+    s.setup_solver = lambda: None
+    s.solve()
+    return snaps

@@ -1,5 +1,8 @@
 """GPU tests at the sizes that are benchmarked (BASELINE.json configs[1] 512^2, configs[2] 64^3) and against the
-committed golden vectors.  The oracle runs the SAME algorithm (GMRES(30) + the same preconditioner construction, NumPy
+committed golden vectors.  Two independent checkers: (1) the oracle redoes ONE step from the GPU's own previous state -- true
+residual of the GPU's solution with the oracle's A and b, and at 512^2 the oracle's sparse direct solve of that step (what the
+reference's direct-solver test pins, tests/KNPEMI/electric_potential_norms_direct_solver.py:55-68): nothing of the product's
+preconditioner enters; (2) the oracle runs the SAME algorithm (GMRES(30) + the same preconditioner construction, NumPy
 V-cycle) for the first two steps -- 7 s / 40 s on one core -- and the GPU path must land on the same potentials to
 1e-6 (north_star tolerance); later steps are checked through invariants the reference states itself:
 sum of the potential unknowns conserved (null-space projection, KNPEMIx_solver.py:297-335), A ns = 0 (:327),
@@ -16,34 +19,28 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
+# Tolerances of the preconditioner-independent check (oracle.single_step_check), measured on one MI355X and written with margin:
+#   * the solve stops on the PRECONDITIONED residual at rtol 1e-9 (reference: ksp_norm_type preconditioned); the true residual is
+#     then 1.9e-6 of ||b|| overall on 512^2 (the oracle's own GMRES leaves the same) and 1.3e-11 normwise backward error
+#     ||r|| / (|| |A||x| || + ||b||) in every one of the 8 field blocks (the phi-rows have an almost empty right-hand side -- membrane
+#     terms only -- so the backward error is the meaningful gate): TRUE_RES / BACKWARD;
+#   * against the oracle's sparse direct solve of the same step: every field to FIELD_TOL of its max norm, ||phi_i|| and phi_m(Gamma)
+#     to the north-star 1e-6.  ||phi_e||_L2 is 200 - 2000x smaller than ||phi_i||_L2 in this problem, so the truncation of ANY rtol-1e-9
+#     solve shows up amplified in its RELATIVE error (the reference's own iterative pin differs from its direct solve by 1e-4 there,
+#     test_oracle_pins.py::test_iterative_pin_noise_floor): the gate on phi_e is |d||phi_e||| <= 1e-6 * ||phi_i||, i.e. 1e-6 of the
+#     potential scale; the 1e-6 RELATIVE statement is checked with the solve tightened to rtol 1e-12 (second test below).
+TRUE_RES, BACKWARD, FIELD_TOL, POT_TOL = 1e-5, 1e-9, 1e-6, 1e-6
+
+
 @pytest.mark.parametrize("kind,N,pc", [("square", 512, "hypre"), ("cube", 64, "btcc")])
 def test_benchmarked_size_matches_oracle_and_invariants(kind, N, pc):
+    import knpemi_oracle as K
+    from parity_utils import make_oracle, run_with_snapshots
     from CGx.KNPEMI.KNPEMIx_solver import SolverKNPEMI
     cfg = ci_config(N=N, steps=3, rtol=1e-9, kind=kind, pc=pc)
     p = make_problem(cfg)
     s = SolverKNPEMI(p, solver_config=p.solver_config)
-    snaps = {}
-    orig_unpack = None
-
-    def run():
-        # SolverKNPEMI.solve with a snapshot after step 2 (the oracle sample) -- same loop, nothing else changed
-        nonlocal orig_unpack
-        s.setup_solver()
-        be = s.backend
-        orig_unpack = be.unpack
-        count = {"i": 0}
-
-        def unpack():
-            orig_unpack()
-            count["i"] += 1
-            if count["i"] == 2:
-                snaps["norms"] = s.potential_norms()
-                snaps["phi_m"] = p.phi_m_prev.numpy().copy()
-                snaps["x"] = be.x.cpu().numpy().copy()
-        be.unpack = unpack
-        s.setup_solver = lambda: None
-        s.solve()
-    run()
+    snaps = run_with_snapshots(s, (2, 3))
     be = s.backend
     assert all(r > 0 for r in s.reasons), s.reasons
     # null space: A ns = 0 to rounding (relative to the largest entry)
@@ -52,18 +49,47 @@ def test_benchmarked_size_matches_oracle_and_invariants(kind, N, pc):
     x = be.x.cpu().numpy()
     n_intra = int((be.node_i >= 0).sum())
     assert abs(x[3::4].sum() - (-0.07 * n_intra)) <= 1e-9 * 0.07 * n_intra
-    # first two steps against the oracle running the same algorithm
+    # (1) PRECONDITIONER-INDEPENDENT: the oracle redoes step 3 from the GPU's state after step 2 -- its own A and b applied to the GPU's x
+    # (true residual per field block), and for the 2D case its sparse direct solve (nested-dissection LU, ~2 min at 512^2; the 64^3
+    # factorisation would take an hour on one core: true residual only)
+    chk = K.single_step_check(make_oracle(N, kind), snaps[2]["state"], snaps[3]["x"], lu=(kind == "square"))
+    print("single-step check:", {k: v for k, v in chk.items() if k != "blocks"}, {k: v["backward"] for k, v in chk["blocks"].items()})
+    assert chk["rel_residual"] <= TRUE_RES and chk["max_backward"] <= BACKWARD and chk["gauge_drift"] <= 1e-10, chk
+    if kind == "square":
+        assert max(chk["lu_field_diff"]) <= FIELD_TOL, chk
+        assert chk["rel_err_phi_i_L2"] <= POT_TOL and chk["rel_err_phi_m_max"] <= POT_TOL, chk
+        assert chk["abs_err_phi_e_over_phi_i"] <= POT_TOL, chk
+    # (2) first two steps against the oracle running the same algorithm: same iteration counts, same iterates
     o, its = oracle_gmres_same_algorithm(kind, N, 2, pc, 1e-9, s)
     assert its == list(s.iterations[:2]), (its, s.iterations)
     oi, oe = o.potential_norms()
-    ni, ne = snaps["norms"]
-    assert abs(ni - oi) <= 1e-6 * oi
-    assert abs(ne - oe) <= 1e-5 * oe          # phi_e is 200x smaller than phi_i here; same algorithm, same iterates
+    ni, ne = snaps[2]["norms"]
+    assert abs(ni - oi) <= POT_TOL * oi
+    assert abs(ne - oe) <= POT_TOL * oi          # 1e-6 of the potential scale (see the note above); same algorithm, same iterates:
+    assert abs(ne - oe) <= 1e-5 * oe             # ... and the relative error stays at the 1e-6 level
     gam = (o.lay.node_i >= 0) & (o.lay.node_e >= 0)
-    assert np.allclose(snaps["phi_m"][gam], o.phi_m[gam], rtol=1e-6, atol=0.0)
+    assert np.allclose(snaps[2]["phi_m"][gam], o.phi_m[gam], rtol=1e-6, atol=0.0)
     xo = o.pack()
     for f in range(4):
-        assert np.max(np.abs(snaps["x"][f::4] - xo[f::4])) <= 1e-8 * np.max(np.abs(xo[f::4])), f
+        assert np.max(np.abs(snaps[2]["x"][f::4] - xo[f::4])) <= 1e-8 * np.max(np.abs(xo[f::4])), f
+
+
+@pytest.mark.parametrize("kind,N,pc", [("square", 128, "hypre"), ("cube", 16, "btcc")])
+def test_tight_solve_reaches_1e6_relative_on_phi_e_against_direct_solve(kind, N, pc):
+    """With the solve tightened to rtol 1e-12 the RELATIVE error of ||phi_e||_L2 against the oracle's direct solve is below the
+    north-star 1e-6 as well (at rtol 1e-9 it is the iterative truncation, not the discretisation or the assembly, that limits it)."""
+    import knpemi_oracle as K
+    from parity_utils import make_oracle, run_with_snapshots
+    from CGx.KNPEMI.KNPEMIx_solver import SolverKNPEMI
+    cfg = ci_config(N=N, steps=3, rtol=1e-12, kind=kind, pc=pc)
+    p = make_problem(cfg)
+    s = SolverKNPEMI(p, solver_config=p.solver_config)
+    snaps = run_with_snapshots(s, (2, 3))
+    assert all(r > 0 for r in s.reasons), s.reasons
+    chk = K.single_step_check(make_oracle(N, kind), snaps[2]["state"], snaps[3]["x"])
+    print("single-step check (rtol 1e-12):", {k: v for k, v in chk.items() if k != "blocks"})
+    assert chk["rel_err_phi_e_L2"] <= 1e-6 and chk["rel_err_phi_i_L2"] <= 1e-8 and chk["rel_err_phi_m_max"] <= 1e-8, chk
+    assert max(chk["lu_field_diff"]) <= 1e-8 and chk["max_backward"] <= 1e-10, chk
 
 
 @pytest.mark.parametrize("name", ["square8_ci", "square8_passive", "cube4_ci"])

@@ -154,3 +154,35 @@ def test_facet_quadrature_exactness():
             c = 10 - a - b
             exact = 2 * factorial(a) * factorial(b) * factorial(c) / factorial(12)
             assert abs((w * pts[:, 0] ** a * pts[:, 1] ** b * pts[:, 2] ** c).sum() - exact) < 1e-15
+
+
+def test_single_step_checker_and_nested_dissection_lu():
+    """The preconditioner-independent checker used at the benchmarked sizes (oracle.single_step_check): fed with the oracle's own
+    GMRES iterate it reports a small true residual per field block and agreement with its direct solve; fed with a perturbed
+    vector it does not.  The nested-dissection LU it uses equals SuperLU's default ordering to the conditioning of the system."""
+    import numpy as np
+    import knpemi_oracle as K
+    from parity_utils import make_oracle
+    o = make_oracle(24, "square")
+    o.run(1)
+    x0, ns = o.pack(), o.nullspace()
+    state = {"k_i": [a.copy() for a in o.k[0]], "k_e": [a.copy() for a in o.k[1]], "phi_i": o.phi[0].copy(), "phi_e": o.phi[1].copy(),
+             "phi_m": o.phi_m.copy(), "n": o.n.copy(), "m": o.m.copy(), "h": o.h.copy(), "t": o.t}
+    A, b = o.step_system()
+    x_col = K.solve_lu_gauge(A, b, ns, ns @ x0)
+    x_nd = K.solve_lu_gauge_nd(A, b, ns, ns @ x0, o.node_coords())
+    for f in range(4):
+        assert np.abs(x_col[f::4] - x_nd[f::4]).max() <= 1e-9 * np.abs(x_col[f::4]).max()
+    perm = K.nested_dissection_order(A, 4, o.node_coords())
+    assert np.array_equal(np.sort(perm), np.arange(A.shape[0]))
+    # candidate = GMRES(30) with the exact-P preconditioner at rtol 1e-10
+    x_it, _, _ = K.gmres_left(A, b, x0, K.pc_exact_lu()(o.assemble_P()), ns=ns, rtol=1e-10)
+    chk = K.single_step_check(make_oracle(24, "square"), state, x_it)
+    assert chk["rel_residual"] <= 1e-8 and chk["max_backward"] <= 1e-9 and chk["gauge_drift"] <= 1e-12
+    assert max(chk["lu_field_diff"]) <= 1e-7 and chk["rel_err_phi_i_L2"] <= 1e-8 and chk["rel_err_phi_m_max"] <= 1e-8
+    assert set(chk["blocks"]) == {"Na_i", "K_i", "Cl_i", "phi_i", "Na_e", "K_e", "Cl_e", "phi_e"}
+    # a wrong candidate is seen: 1e-4 relative perturbation of the extracellular potential
+    x_bad = x_it.copy()
+    x_bad[3::4] *= 1.0 + 1e-4 * np.sin(np.arange(x_bad[3::4].size))
+    bad = K.single_step_check(make_oracle(24, "square"), state, x_bad)
+    assert bad["max_backward"] > 1e-6 and bad["lu_field_diff"][3] > 1e-5
