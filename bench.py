@@ -41,10 +41,10 @@ MAX_REPS = 40
 PARITY_TOL = 1e-6         # north_star: potentials match the reference solve to rtol 1e-6
 # True residual of the sampled step with the ORACLE's A and b.  The solve stops on the PRECONDITIONED residual at rtol 1e-9 (reference:
 # ksp_norm_type preconditioned), which leaves 2e-6 of ||b|| overall on 512^2 (measured; the oracle's own GMRES leaves the same) and
-# 1e-11 normwise backward error ||r|| / (|| |A||x| || + ||b||) in every field block -- the phi-rows have an almost empty right-hand side
+# 1e-11 (512^2) to 1e-9 (64^3 with btcc) normwise backward error ||r|| / (|| |A||x| || + ||b||) in every field block -- the phi-rows have an almost empty right-hand side
 # (membrane terms only), so only the backward error is a meaningful gate there.
 TRUE_RES_TOL = 1e-5
-BACKWARD_TOL = 1e-9
+BACKWARD_TOL = 1e-8
 
 
 def parse():

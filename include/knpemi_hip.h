@@ -13,6 +13,7 @@
  *        the FFCx-JIT-compiled membrane integrands built from IonicModel._eval
  *        (KNPEMIx_problem.py:504-555, 609-610, 641-642; KNPEMIx_ionic_model.py:_eval methods)
  *   knp_assemble_matrix              assemble_matrix_block(A, a)      (KNPEMIx_solver.py:110-115)
+ *   knp_assemble_matrix_async        the same, next to the right-hand side chain (own stream)
  *   knp_assemble_rhs                 assemble_vector_block(b, L, a)   (KNPEMIx_solver.py:116)
  *   knp_assemble_precond             assemble_matrix_block(P)         (KNPEMIx_solver.py:118-127,
  *                                    form KNPEMIx_problem.py:657-744)
@@ -222,6 +223,11 @@ int knp_set_sources(knp_ctx* ctx, const double* const* f_i, const double* const*
 
 /* ---- per-timestep assembly ---- */
 int knp_assemble_matrix(knp_ctx* ctx, const knp_fields* fields);
+/* the same assembly (assemble_matrix_block(A, a), KNPEMIx_solver.py:110-115) on the library's own stream: A depends on the previous
+ * solution only, so the right-hand side chain of the step (gating update, knp_assemble_rhs, knp_gmres_prepare) can be enqueued
+ * while it runs.  The fields must not be modified until the next call that needs A (knp_gmres_solve, knp_spmv, exports), which
+ * joins it.  In line (== knp_assemble_matrix) on the first assembly, with vertex-block Jacobi or when kernel classes are timed. */
+int knp_assemble_matrix_async(knp_ctx* ctx, const knp_fields* fields);
 int knp_assemble_rhs(knp_ctx* ctx, const knp_fields* fields, double* b /* device [n_dof_local] */);
 int knp_assemble_precond(knp_ctx* ctx, const knp_fields* fields);
 
@@ -300,6 +306,13 @@ int knp_l2_norms(knp_ctx* ctx, const double* phi_i, const double* phi_e, double*
 /* ---- instrumentation ---- */
 /* elapsed ms and launch count of a kernel class since the last reset (HIP events on the ctx stream).
  * classes: 0 spmv, 1 orthogonalisation, 2 pc, 3 assembly, 4 other */
+/* step timers of the host loop (reference: perf_counter + allreduce(MAX) around assembly and solve, KNPEMIx_solver.py:402-413,
+ * 434-449): knp_timer_mark records one event on the stream (join_assembly != 0: after joining knp_assemble_matrix_async);
+ * knp_timer_read synchronises once and returns the seconds between consecutive marks (n marks -> n - 1 intervals), then
+ * forgets them; knp_timer_pending = marks recorded and not yet read. */
+int knp_timer_mark(knp_ctx* ctx, int32_t join_assembly);
+int knp_timer_read(knp_ctx* ctx, int32_t capacity, double* seconds /* host [capacity] */, int32_t* n_intervals);
+int knp_timer_pending(const knp_ctx* ctx);
 int knp_profile_enable(knp_ctx* ctx, int32_t class_mask); /* bit k enables class k; 0 disables */
 int knp_profile_get(knp_ctx* ctx, int32_t cls, double* ms, int64_t* launches);
 int knp_profile_reset(knp_ctx* ctx);

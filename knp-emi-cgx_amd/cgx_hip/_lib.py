@@ -73,6 +73,7 @@ SIGNATURES = {
     "knp_set_dirichlet": (C.c_int, [vp, C.c_int32, i32p]),
     "knp_set_sources": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp)]),
     "knp_assemble_matrix": (C.c_int, [vp, C.POINTER(Fields)]),
+    "knp_assemble_matrix_async": (C.c_int, [vp, C.POINTER(Fields)]),
     "knp_assemble_rhs": (C.c_int, [vp, C.POINTER(Fields), vp]),
     "knp_assemble_precond": (C.c_int, [vp, C.POINTER(Fields)]),
     "knp_spmv": (C.c_int, [vp, vp, vp]),
@@ -110,6 +111,9 @@ SIGNATURES = {
     "knp_unpack": (C.c_int, [vp, vp, C.POINTER(FieldsOut)]),
     "knp_hh_update": (C.c_int, [vp, vp, vp, vp, vp, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int32]),
     "knp_l2_norms": (C.c_int, [vp, vp, vp, f64p]),
+    "knp_timer_mark": (C.c_int, [vp, C.c_int32]),
+    "knp_timer_read": (C.c_int, [vp, C.c_int32, f64p, C.POINTER(C.c_int32)]),
+    "knp_timer_pending": (C.c_int, [vp]),
     "knp_profile_enable": (C.c_int, [vp, C.c_int32]),
     "knp_profile_get": (C.c_int, [vp, C.c_int32, f64p, i64p]),
     "knp_profile_reset": (C.c_int, [vp]),

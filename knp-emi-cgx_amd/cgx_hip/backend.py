@@ -400,7 +400,11 @@ class Backend:
                 self.check(self.lib.knp_set_program_constants(self.ctx, int(pid), consts.shape[0], _f64(consts)))
 
     def fields(self):
+        """the nodal input fields as the ABI's struct of device pointers (built once: the tensors behind wh / phi_m / aux never move)"""
         p = self.p
+        key = tuple(id(fn) for fn in getattr(p, "aux_functions", []))
+        if getattr(self, "_fields_cache", None) is not None and self._fields_key == key:
+            return self._fields_cache
         f = Fields()
         for j in range(3):
             f.k_i[j] = p.wh[0][j].data_ptr()
@@ -408,10 +412,13 @@ class Backend:
         f.phi_m = p.phi_m_prev.data_ptr()
         for k, fn in enumerate(getattr(p, "aux_functions", [])):
             f.aux[k] = fn.data_ptr()
+        self._fields_cache, self._fields_key = f, key
         return f
 
     def fields_out(self):
         p = self.p
+        if getattr(self, "_fields_out_cache", None) is not None:
+            return self._fields_out_cache
         f = FieldsOut()
         for j in range(3):
             f.k_i[j] = p.wh[0][j].data_ptr()
@@ -419,12 +426,18 @@ class Backend:
         f.phi_i = p.wh[0][3].data_ptr()
         f.phi_e = p.wh[1][3].data_ptr()
         f.phi_m = p.phi_m_prev.data_ptr()
+        self._fields_out_cache = f
         return f
 
     # ------------------------------------------------------------------ operations
     def assemble_matrix(self):
         f = self.fields()
         self.check(self.lib.knp_assemble_matrix(self.ctx, C.byref(f)))
+
+    def assemble_matrix_async(self):
+        """matrix assembly on the library's own stream (next to the right-hand side chain of the same step); joined by the solve"""
+        f = self.fields()
+        self.check(self.lib.knp_assemble_matrix_async(self.ctx, C.byref(f)))
 
     def assemble_rhs(self):
         if not getattr(self, "_programs_uploaded", False):
@@ -521,6 +534,27 @@ class Backend:
         P = sp.csr_matrix((va, ci, rp), shape=(self.n_dof_owned, self.n_dof_local))
         P.sort_indices()
         return P
+
+    # ---- step timers (events in the library: one ctypes call per mark, one synchronisation per read) ------------------------
+    def timer_mark(self, join_assembly=False):
+        self.check(self.lib.knp_timer_mark(self.ctx, 1 if join_assembly else 0))
+
+    def timer_pending(self):
+        return int(self.lib.knp_timer_pending(self.ctx))
+
+    def timer_read(self):
+        """seconds between consecutive marks since the last read (synchronises on the last mark)"""
+        n = self.timer_pending()
+        if n < 2:
+            if n:
+                out = (C.c_double * 1)()
+                k = C.c_int32()
+                self.check(self.lib.knp_timer_read(self.ctx, 1, out, C.byref(k)))
+            return np.zeros(0)
+        out = (C.c_double * n)()
+        k = C.c_int32()
+        self.check(self.lib.knp_timer_read(self.ctx, n, out, C.byref(k)))
+        return np.array(out[:k.value], dtype=np.float64)
 
     # ---- instrumentation -----------------------------------------------------------------
     def profile_enable(self, mask=0x1f):

@@ -138,8 +138,12 @@ class SolverKNPEMI:
         self.print("Assembling linear system ...")
         be = self.backend
         p = self.problem
-        # right-hand side first: its preconditioned norm (the first thing the solve needs) then runs on a side stream
-        # while the matrix is assembled (the reference assembles A then b, :114-116; the two are independent)
+        # A and b are independent (the reference assembles A then b, :114-116): the matrix is assembled on the library's own stream
+        # while the right-hand side chain runs on this one; the preconditioned norm of b (the first thing the solve needs) then
+        # starts on a third stream and overlaps both, the solve's first SpMV and its first preconditioner application
+        async_matrix = self._b_is_final and not p.MMS_test
+        if async_matrix:
+            be.assemble_matrix_async()
         be.assemble_rhs()
         if p.MMS_test:
             # extra terms of L for the manufactured solution (KNPEMIx_problem.py:616-651): host integrals of the
@@ -152,7 +156,8 @@ class SolverKNPEMI:
         be.apply_dirichlet_rhs()
         if self._b_is_final:
             be.gmres_prepare()
-        be.assemble_matrix()
+        if not async_matrix:
+            be.assemble_matrix()
 
     # ---- reference :118-135
     def assemble_preconditioner(self):
@@ -331,30 +336,27 @@ class SolverKNPEMI:
             self._sync()
             self.setup_breakdown["preconditioner_setup_s"] = self.comm.allreduce_max(time.perf_counter() - tic)
             self._setup_timer += self.setup_breakdown["preconditioner_setup_s"]
-        self._events = []
-        self._resolved = 0
+        self._n_marked = 0
         self._prepared = True
 
-    def _mark(self):
-        ev = torch.cuda.Event(enable_timing=True)
-        ev.record()
-        return ev
-
     def _resolve_timers(self):
-        """Read the event timers of the steps not yet accounted for (one synchronisation) and append them to ``ode_time``,
-        ``assembly_time`` and ``solve_time`` -- MAX over the ranks, as the reference's allreduce does."""
-        evs = self._events
-        if not evs:
+        """Read the step timers not yet accounted for (one synchronisation: ``knp_timer_read``) and append them to ``ode_time``,
+        ``assembly_time`` and ``solve_time`` -- MAX over the ranks, as the reference's allreduce does.  Four marks per step:
+        start | gating done | assembly done (both streams joined) | solve done."""
+        if not getattr(self, "_n_marked", 0):
             return
-        evs[-1][-1].synchronize()
-        rows = [[a.elapsed_time(b) * 1e-3 for a, b in zip(e[:-1], e[1:])] for e in evs]      # [ode, assembly, (null space), solve]
-        self._events = []
-        arr = np.asarray(rows, dtype=np.float64)
+        dts = self.backend.timer_read()
+        n_steps, self._n_marked = self._n_marked, 0
+        if dts.size < 4 * n_steps - 1:
+            return
+        arr = np.zeros((n_steps, 3))
+        for k in range(n_steps):
+            arr[k] = dts[4 * k:4 * k + 3]            # (the fourth interval of a step is unpack + output + the host's next-step work)
         if self.comm.size > 1:
             tt = torch.as_tensor(arr, device=self.backend.device)
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
             arr = tt.cpu().numpy()
-        for ode, asm, _, sol in arr:
+        for ode, asm, sol in arr:
             if self.problem.gating_variables:
                 self.ode_time.append(float(ode))
             self.assembly_time.append(float(asm))
@@ -380,18 +382,18 @@ class SolverKNPEMI:
                 self.view()
             tic = time.perf_counter()
 
-        e0 = self._mark()
+        be.timer_mark()
         if p.gating_variables:
             for model in p.ionic_models:
                 if isinstance(model, HodgkinHuxley):
                     model.update_t_mod()
                     model.update_gating_variables()
-        e1 = self._mark()
+        be.timer_mark()
         self._b_is_final = i > 1          # step 1: the null-space projection still modifies b after the assembly
         self.assemble()
         if i > 1 and self.reassemble_P and (i % self.reassemble_N == 0) and self.use_P_mat and self._pc_kind in (_lib.PC_AMG, _lib.PC_AMG_BT, _lib.PC_AMG_LT):
             self.reassemble_preconditioner()
-        e2 = self._mark()
+        be.timer_mark(join_assembly=True)
         if i == 1:
             self._sync()                      # first assembly: run-time compilation of the membrane programs, first launches
             self.setup_breakdown["first_assembly_s"] = self.comm.allreduce_max(time.perf_counter() - tic)
@@ -408,7 +410,6 @@ class SolverKNPEMI:
             np.save(self.out_file_prefix + "Amat", np.c_[A.row, A.col, A.data])
             return False
 
-        e3 = self._mark()
         its, rnorm, reason = be.gmres(self._rtol, 1e-50, self.ksp_max_it, self.gmres_restart)
         self.ksp.its, self.ksp.rnorm, self.ksp.reason = its, rnorm, reason
         self.tot_its += its
@@ -417,15 +418,15 @@ class SolverKNPEMI:
             # component from the SOLUTION, i.e. the potentials come back with zero mean over all potential unknowns --
             # the gauge of the reference's direct-solver pins (tests/test_oracle_pins.py::test_direct_solver_pin_without_any_fit)
             be.project_nullspace(be.x)
-        e4 = self._mark()
-        self._events.append((e0, e1, e2, e3, e4))
+        be.timer_mark()
+        self._n_marked += 1
         self.iterations.append(its)
         self.reasons.append(reason)
         if not getattr(p, "quiet", False):        # the reference prints both timers at every step: read them now
             self._resolve_timers()
             self.print(f"Time dependent assembly in {self.assembly_time[-1]:0.4f} seconds")
             self.print(f"Solved in {self.solve_time[-1]:0.4f} seconds ({its} its, {_lib.REASONS.get(reason, reason)}, |r| = {rnorm:.3e})")
-        elif len(self._events) >= 512:
+        elif self._n_marked >= 512:
             self._resolve_timers()
         if reason < 0 and self.strict:
             raise RuntimeError(f"GMRES did not converge at step {i}: {_lib.REASONS.get(reason, reason)}")

@@ -134,6 +134,7 @@ struct KnpAmgLevel {
     int32_t *R_rp = nullptr, *R_ci = nullptr;
     double* R_v = nullptr;
     double *x = nullptr, *b = nullptr, *r = nullptr, *d = nullptr, *r2 = nullptr;  // work vectors (x / r2 ping-pong)
+    double *xs = nullptr, *bs = nullptr, *rs = nullptr, *ds = nullptr, *r2s = nullptr;   // second set: the side-stream cycle of knp_gmres_prepare
     int A_lanes = 8, P_lanes = 4, R_lanes = 8;
     // fused cycle: S = (I - c2 Dinv A) Pprol, rows = this level's rows (compact list of the non-empty ones when S_n_act > 0)
     int32_t *S_rp = nullptr, *S_ci = nullptr;
@@ -303,9 +304,23 @@ struct knp_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     const double* prep_b = nullptr;
     int prep_fused = 0;   // the side-stream ||B b|| used the one-reduction projected norm (flag in slot 61)
+    // Concurrent form (one GPU, fused cycle, null space on): the side-stream cycle works on its OWN vectors, partial sums and
+    // reduction slots, so it may still be running while the solve computes its first preconditioned residual on the main
+    // stream; the solve only joins it when it needs ||B b||, after its first read-back.
+    int prep_conc = 0;
+    bool prep_deferred = false;   // concurrent form: the side-stream cycle is enqueued by the solve, behind its own first residual chain
+    bool side_ws = false;
+    double *d_t2_s = nullptr, *d_w2_s = nullptr, *d_wb = nullptr, *d_partial_s = nullptr;
+    // matrix assembly on its own stream (knp_assemble_matrix_async): independent of the right-hand side chain of the same step
+    hipStream_t stream_asm = nullptr;
+    hipEvent_t ev_fork_asm = nullptr, ev_asm = nullptr;
+    bool asm_pending = false;
     // statistics of the solves (knp_get_stats): ||B b|| of the last solve, exchanges and host read-backs since the last reset
     double last_bnorm = 0.0;
     int64_t n_allreduce = 0, n_halo = 0, n_readback = 0;
+    // step timers (knp_timer_mark / knp_timer_read): timing events recorded on the main stream, read back in one go
+    std::vector<hipEvent_t> tm_events;
+    size_t tm_used = 0;
     // profiling
     int prof_on = 0;
     std::vector<hipEvent_t> prof_pool;   // recycled timing events

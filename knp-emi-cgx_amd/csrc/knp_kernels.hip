@@ -48,6 +48,7 @@ static constexpr int RED_BLOCKS = 1024; // reduction partial blocks (4 per CU on
 static constexpr int RED_SLOTS = 128;   // reduced-value slots: 0..56 Gram-Schmidt, 58..63 misc, 64..95 deflation sums
 static constexpr int DEFL_SLOT0 = 64;
 static constexpr int DEFL_MAX = 32;
+static constexpr int SIDE_SLOT = 120;  // 120..123: {norm, flag, phi sum, w.w} of the side-stream ||B b|| (concurrent knp_gmres_prepare)
 
 struct DevParams {
     double dt, F, C_M, psi;
@@ -61,6 +62,7 @@ struct FieldPtrs {
 };
 
 static void side_discard(knp_ctx* ctx);
+static int join_asm(knp_ctx* ctx);
 static void free_hier(KnpAmgHier& H);
 static inline int nblocks(int64_t n, int per = NT) { return (int)std::max<int64_t>(1, (n + per - 1) / per); }
 
@@ -2197,6 +2199,8 @@ struct ProfScope {
 static int prof_collect(knp_ctx* ctx) {
     if (ctx->prof_recs.empty()) return KNP_OK;
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->stream2) HIPCHK(hipStreamSynchronize(ctx->stream2));
+    if (ctx->stream_asm) HIPCHK(hipStreamSynchronize(ctx->stream_asm));
     for (auto& r : ctx->prof_recs) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
@@ -2436,11 +2440,14 @@ int knp_destroy(knp_ctx* ctx) {
     (void)hipDeviceSynchronize();
     if (ctx->stream2) { (void)hipEventDestroy(ctx->ev_fork); (void)hipEventDestroy(ctx->ev_join); (void)hipStreamDestroy(ctx->stream2); }
     if (ctx->stream3) { (void)hipEventDestroy(ctx->ev_x); (void)hipEventDestroy(ctx->ev_halo); (void)hipStreamDestroy(ctx->stream3); }
+    if (ctx->stream_asm) { (void)hipEventDestroy(ctx->ev_fork_asm); (void)hipEventDestroy(ctx->ev_asm); (void)hipStreamDestroy(ctx->stream_asm); }
+    dev_free(ctx->d_t2_s); dev_free(ctx->d_w2_s); dev_free(ctx->d_wb); dev_free(ctx->d_partial_s);
     dev_free(ctx->d_nodes_int); dev_free(ctx->d_nodes_bnd);
     knp_p2p_free(ctx);
     knp_jit_release(ctx);
     for (auto& r : ctx->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto& e : ctx->prof_pool) (void)hipEventDestroy(e);
+    for (auto& e : ctx->tm_events) (void)hipEventDestroy(e);
     dev_free(ctx->d_cells); dev_free(ctx->d_cell_side); dev_free(ctx->d_coords);
     dev_free(ctx->d_node_vertex); dev_free(ctx->d_node_side); dev_free(ctx->d_node_i); dev_free(ctx->d_node_e);
     dev_free(ctx->d_pair_ptr); dev_free(ctx->d_pair_col); dev_free(ctx->d_pair_row);
@@ -2516,6 +2523,7 @@ int knp_get_csr_values(const knp_ctx* cctx, double* vals) {
     knp_ctx* ctx = const_cast<knp_ctx*>(cctx);
     if (!ctx || !vals) return KNP_E_ARG;
     KCHK(knp_build_csr_pattern(ctx->g));
+    KCHK(join_asm(ctx));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     const KnpHostGraph& g = ctx->g;
     std::vector<double> at((size_t)4 * ctx->n_pairs), ac((size_t)6 * ctx->n_pairs), ax((size_t)8 * ctx->n_gp);
@@ -2565,6 +2573,7 @@ int knp_matrix_max_abs(knp_ctx* ctx, double* out) {
     if (!out) return KNP_E_ARG;
     if (!ctx->have_A) { ctx->err = "matrix not assembled"; return KNP_E_STATE; }
     side_discard(ctx);   // d_partial is also the side stream's reduction scratch (knp_gmres_prepare)
+    KCHK(join_asm(ctx));
     const double* arr[3] = {ctx->d_at, ctx->d_ac, ctx->d_ax};
     const int64_t len[3] = {4 * ctx->n_pairs, 6 * ctx->n_pairs, 8 * ctx->n_gp};
     std::vector<double> h(3 * RED_BLOCKS, 0.0);
@@ -2726,9 +2735,17 @@ static void launch_schur_diag(knp_ctx* ctx, const FieldPtrs& f) {
     ctx->have_cc = true;
 }
 
-int knp_assemble_matrix(knp_ctx* ctx, const knp_fields* fields) {
-    CHECK_CTX(ctx);
-    KCHK(check_fields(ctx, fields, false));
+// join the matrix assembly that runs on its own stream (knp_assemble_matrix_async): everything that reads A, or writes what
+// that assembly reads or uses as scratch (the cell means, the facet matrices), calls this first
+static int join_asm(knp_ctx* ctx) {
+    if (ctx->asm_pending) {
+        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_asm, 0));
+        ctx->asm_pending = false;
+    }
+    return KNP_OK;
+}
+
+static int assemble_matrix_on_stream(knp_ctx* ctx, const knp_fields* fields, bool with_schur_diag) {
     const KnpHostGraph& g = ctx->g;
     const DevParams P = make_params(ctx);
     FieldPtrs f = make_fields(fields);
@@ -2768,8 +2785,9 @@ int knp_assemble_matrix(knp_ctx* ctx, const knp_fields* fields) {
         hipLaunchKernelGGL(k_dirichlet_rows_A, dim3(nblocks(ctx->n_bc)), dim3(NT), 0, ctx->stream, ctx->n_bc, ctx->d_bc_dofs, ctx->d_pair_ptr,
                            ctx->d_pair_col, ctx->d_node_gv, ctx->d_node_side, ctx->d_gptr, ctx->d_ac, ctx->d_at, ctx->d_ax);
     // The Schur diagonal depends on the fields only.  knp_assemble_rhs of the same step has already written it; while a
-    // side-stream preconditioner application (knp_gmres_prepare) is in flight it READS d_cc, so it must not be rewritten here.
-    if (!ctx->prep_b) launch_schur_diag(ctx, f);
+    // side-stream preconditioner application (knp_gmres_prepare) is in flight it READS d_cc, so it must not be rewritten here
+    // (nor by the asynchronous form, which runs next to the right-hand side assembly that writes it).
+    if (with_schur_diag && !ctx->prep_b) launch_schur_diag(ctx, f);
     HIPCHK(hipGetLastError());
     ctx->have_A = true;
     if (ctx->pc_kind == KNP_PC_VBJACOBI) {
@@ -2781,9 +2799,45 @@ int knp_assemble_matrix(knp_ctx* ctx, const knp_fields* fields) {
     return KNP_OK;
 }
 
+int knp_assemble_matrix(knp_ctx* ctx, const knp_fields* fields) {
+    CHECK_CTX(ctx);
+    KCHK(check_fields(ctx, fields, false));
+    KCHK(join_asm(ctx));
+    return assemble_matrix_on_stream(ctx, fields, true);
+}
+
+// The same assembly on the library's own stream: it depends on the previous solution only, not on the gating update or the
+// right-hand side of the step, so the caller may enqueue the right-hand side chain (and knp_gmres_prepare) on the main stream
+// while it runs.  Every later call that needs A joins it (join_asm).  Falls back to the in-line form where the matrix is consumed
+// at once (vertex-block Jacobi extracts its blocks) or every kernel class is being timed.
+int knp_assemble_matrix_async(knp_ctx* ctx, const knp_fields* fields) {
+    CHECK_CTX(ctx);
+    KCHK(check_fields(ctx, fields, false));
+    KCHK(join_asm(ctx));
+    static const bool off = getenv("KNP_ASM_ASYNC") && atoi(getenv("KNP_ASM_ASYNC")) == 0;
+    if (off || ctx->pc_kind == KNP_PC_VBJACOBI || (ctx->prof_on & ~1) || !ctx->have_A || ctx->prep_b)
+        return assemble_matrix_on_stream(ctx, fields, true);
+    if (!ctx->stream_asm) {
+        HIPCHK(hipStreamCreateWithFlags(&ctx->stream_asm, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork_asm, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ctx->ev_asm, hipEventDisableTiming));
+    }
+    HIPCHK(hipEventRecord(ctx->ev_fork_asm, ctx->stream));            // after everything that wrote the fields (unpack)
+    HIPCHK(hipStreamWaitEvent(ctx->stream_asm, ctx->ev_fork_asm, 0));
+    hipStream_t main_stream = ctx->stream;
+    ctx->stream = ctx->stream_asm;
+    const int rc = assemble_matrix_on_stream(ctx, fields, false);
+    ctx->stream = main_stream;
+    KCHK(rc);
+    HIPCHK(hipEventRecord(ctx->ev_asm, ctx->stream_asm));
+    ctx->asm_pending = true;
+    return KNP_OK;
+}
+
 int knp_assemble_precond(knp_ctx* ctx, const knp_fields* fields) {
     CHECK_CTX(ctx);
     side_discard(ctx);
+    KCHK(join_asm(ctx));
     KCHK(check_fields(ctx, fields, false));
     const KnpHostGraph& g = ctx->g;
     const DevParams P = make_params(ctx);
@@ -3012,6 +3066,7 @@ static int ensure_work(knp_ctx* ctx, int restart) {
 
 static int spmv_A(knp_ctx* ctx, double* x, const double* b, double* y, bool residual) {
     const KnpHostGraph& g = ctx->g;
+    KCHK(join_asm(ctx));
     hipEvent_t ea = nullptr, eb = nullptr;
     if (ctx->prof_on & 1) {   // class 0: events tied to the kernel's begin / end (recycled: no event creation in the timed loop)
         ea = prof_event(ctx);
@@ -3153,6 +3208,7 @@ static void free_hier(KnpAmgHier& H) {
         dev_free(L.P_rp); dev_free(L.P_ci); dev_free(L.P_v); dev_free(L.R_rp); dev_free(L.R_ci); dev_free(L.R_v);
         dev_free(L.A_vf); dev_free(L.P_vf); dev_free(L.R_vf); dev_free(L.P_act_rows); dev_free(L.P_act_rp); L.P_n_act = 0;
         dev_free(L.x); dev_free(L.b); dev_free(L.r); dev_free(L.d); dev_free(L.r2);
+        dev_free(L.xs); dev_free(L.bs); dev_free(L.rs); dev_free(L.ds); dev_free(L.r2s);
         dev_free(L.S_rp); dev_free(L.S_ci); dev_free(L.S_v); dev_free(L.S_vf); dev_free(L.S_act_rows); dev_free(L.S_act_rp);
         dev_free(L.R_ci_c); dev_free(L.S_act_rows_c); dev_free(L.dinv_c);
         free_blocked(L.bA); free_blocked(L.bR); free_blocked(L.bS);
@@ -3732,6 +3788,7 @@ static int build_level_scaled(knp_ctx* ctx, int hidx, int l) {
 int knp_pc_setup(knp_ctx* ctx, int32_t kind) {
     CHECK_CTX(ctx);
     side_discard(ctx);
+    KCHK(join_asm(ctx));
     if (kind != KNP_PC_NONE && kind != KNP_PC_VBJACOBI && kind != KNP_PC_AMG && kind != KNP_PC_AMG_BT && kind != KNP_PC_AMG_LT) { ctx->err = "unknown pc kind"; return KNP_E_ARG; }
     if (kind == KNP_PC_AMG) KCHK(check_hier(ctx, 0));
     if (kind == KNP_PC_AMG_BT || kind == KNP_PC_AMG_LT) {
@@ -3927,8 +3984,9 @@ int knp_pc_apply(knp_ctx* ctx, const double* r, double* z) {
 // coarse levels are launch-latency bound, the assembly is bandwidth bound).
 static void side_discard(knp_ctx* ctx) {   // any call that could touch what the side stream uses joins it first
     if (ctx->prep_b) {
-        (void)hipEventSynchronize(ctx->ev_join);
+        if (!ctx->prep_deferred) (void)hipEventSynchronize(ctx->ev_join);   // deferred: nothing was enqueued yet
         ctx->prep_b = nullptr;
+        ctx->prep_deferred = false;
     }
 }
 
@@ -3948,9 +4006,29 @@ static bool exchanges_all_native(const knp_ctx* ctx) {
 // together and |z - ns (ns.z)|^2 = z.z - s^2/cnt (k_proj_norm; slot 60 = the norm, 61 = its cancellation flag, 62 = s).  z itself is
 // left UNPROJECTED (*fused = true): the caller subtracts the mean when it normalises (k_scale_rsqrt_proj) or does not need z at
 // all (||B b||).  Without a null space: the plain sequence, *fused = false.
-static int pc_apply_norm(knp_ctx* ctx, const double* r, double* z, int64_t cnt, bool* fused) {
+static bool fused_norm_possible(const knp_ctx* ctx, int64_t cnt) {
     static const bool off = getenv("KNP_NO_FUSED_NORM") != nullptr;
-    if (!(ctx->ns_on && cnt > 0) || off || ctx->defl_m > 0) {
+    return ctx->ns_on && cnt > 0 && !off && ctx->defl_m == 0;
+}
+// side = true: the side-stream form of knp_gmres_prepare's concurrent mode -- partial sums in d_partial_s, reduced values in slots
+// 122/123 -> {norm, flag} in 120/121 (+ pinned mirror), and NO sequence word (the solve joins it with an event): nothing the main
+// stream uses is touched.  Requires fused_norm_possible.
+static int pc_apply_norm(knp_ctx* ctx, const double* r, double* z, int64_t cnt, bool* fused, bool side = false) {
+    if (side) {
+        *fused = true;
+        KCHK(pc_apply_proj(ctx, r, z, 0));
+        ProfScope ps(ctx, 1);
+        const int nb = ctx->n_red_blocks;
+        hipLaunchKernelGGL((k_multi_dot<8, true, true>), dim3(nb), dim3(NT), 0, ctx->stream, ctx->n_dof_owned, (int64_t)ctx->n_dof_local, 0, 0,
+                           ctx->d_V, z, ctx->d_partial_s);
+        hipLaunchKernelGGL(k_reduce_partials, dim3(2), dim3(NT), 0, ctx->stream, nb, ctx->d_partial_s, ctx->d_red, SIDE_SLOT + 2, (double*)nullptr);
+        ++ctx->n_allreduce;
+        hipLaunchKernelGGL(k_proj_norm, dim3(1), dim3(64), 0, ctx->stream, ctx->d_red, SIDE_SLOT + 2, SIDE_SLOT, 1.0 / (double)cnt, GM_CANCEL, ctx->mirror(),
+                           (volatile int64_t*)nullptr, (int64_t)0);
+        HIPCHK(hipGetLastError());
+        return KNP_OK;
+    }
+    if (!fused_norm_possible(ctx, cnt)) {
         *fused = false;
         KCHK(pc_apply_proj(ctx, r, z, cnt));
         return dot_to_slot(ctx, z, z, 60);
@@ -3982,6 +4060,49 @@ static int pc_norm_read(knp_ctx* ctx, double* z, int64_t cnt, bool* fused) {
     return KNP_OK;
 }
 
+// second set of work vectors for the cycle that runs on the side stream while the main stream applies the same hierarchies
+static int ensure_side_ws(knp_ctx* ctx) {
+    if (ctx->side_ws) return KNP_OK;
+    auto zalloc = [&](double** p, size_t n) -> int {
+        HIPCHK(hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(double)));
+        HIPCHK(hipMemsetAsync(*p, 0, std::max<size_t>(n, 1) * sizeof(double), ctx->stream));
+        return KNP_OK;
+    };
+    for (int h = 0; h < KNP_MAX_HIER; ++h)
+        for (int l = 0; l < ctx->hier[h].levels; ++l) {
+            KnpAmgLevel& L = ctx->hier[h].lv[l];
+            const size_t n = (size_t)std::max(L.n_loc, L.n);
+            if (L.xs || n == 0) continue;
+            KCHK(zalloc(&L.xs, n)); KCHK(zalloc(&L.bs, n)); KCHK(zalloc(&L.rs, n)); KCHK(zalloc(&L.ds, n)); KCHK(zalloc(&L.r2s, n));
+        }
+    const size_t nl = (size_t)std::max(ctx->n_dof_local, 1);
+    if (!ctx->d_t2_s) { KCHK(zalloc(&ctx->d_t2_s, nl)); KCHK(zalloc(&ctx->d_w2_s, nl)); }
+    if (!ctx->d_wb) KCHK(zalloc(&ctx->d_wb, nl));
+    if (!ctx->d_partial_s) KCHK(zalloc(&ctx->d_partial_s, (size_t)RED_SLOTS * RED_BLOCKS));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->side_ws = true;
+    return KNP_OK;
+}
+static void swap_side_ws(knp_ctx* ctx) {   // host-side pointer swap: kernel arguments are taken at launch
+    for (int h = 0; h < KNP_MAX_HIER; ++h)
+        for (int l = 0; l < ctx->hier[h].levels; ++l) {
+            KnpAmgLevel& L = ctx->hier[h].lv[l];
+            if (!L.xs) continue;
+            std::swap(L.x, L.xs); std::swap(L.b, L.bs); std::swap(L.r, L.rs); std::swap(L.d, L.ds); std::swap(L.r2, L.r2s);
+        }
+    if (ctx->d_t2 && ctx->d_t2_s) { std::swap(ctx->d_t2, ctx->d_t2_s); std::swap(ctx->d_w2, ctx->d_w2_s); }
+}
+// the side-stream cycle may run next to the solve's own first preconditioner application: one GPU, fused cycles (their work
+// vectors are exactly the per-level sets swapped above), gauge-projected norm from one reduction, pinned mirror for the result
+static bool side_concurrent_ok(const knp_ctx* ctx, int64_t cnt) {
+    static const bool off = getenv("KNP_SIDE_CONCURRENT") && atoi(getenv("KNP_SIDE_CONCURRENT")) == 0;
+    if (off || ctx->halo || ctx->allreduce || ctx->level_comm || ctx->p2p || ctx->n_bc > 0 || !ctx->h_red_dev) return false;
+    if (!fused_norm_possible(ctx, cnt)) return false;
+    if (ctx->pc_kind == KNP_PC_AMG) return ctx->hier[0].fused != 0;
+    if (ctx->pc_kind == KNP_PC_AMG_BT || ctx->pc_kind == KNP_PC_AMG_LT) return ctx->hier[0].fused && ctx->hier[1].fused;
+    return false;
+}
+
 int knp_gmres_prepare(knp_ctx* ctx, const double* b) {
     CHECK_CTX(ctx);
     if (!b) return KNP_E_ARG;
@@ -4004,13 +4125,26 @@ int knp_gmres_prepare(knp_ctx* ctx, const double* b) {
     int rc = KNP_OK;
     const int64_t cnt = ctx->ns_on ? global_phi_count(ctx, &rc) : 0;
     KCHK(rc);
+    const bool conc = side_concurrent_ok(ctx, cnt);
     HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
+    if (conc) {
+        // Concurrent form: only the fork point is fixed here (b is final).  The cycle itself is enqueued by knp_gmres_solve BEHIND the
+        // launches of its own first residual chain, so that the host feeds the critical path first and this cycle overlaps it.
+        KCHK(ensure_side_ws(ctx));
+        ctx->prep_fused = 1;
+        ctx->prep_conc = 1;
+        ctx->prep_deferred = true;
+        ctx->prep_b = b;
+        return KNP_OK;
+    }
     HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
     hipStream_t main_stream = ctx->stream;
     ctx->stream = ctx->stream2;
     bool fused_norm = false;
     rc = pc_apply_norm(ctx, b, ctx->d_w, cnt, &fused_norm);
     ctx->prep_fused = fused_norm ? 1 : 0;
+    ctx->prep_conc = 0;
+    ctx->prep_deferred = false;
     ctx->stream = main_stream;
     KCHK(rc);
     HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
@@ -4069,7 +4203,11 @@ int knp_gmres_solve(knp_ctx* ctx, const double* b, double* x, double rtol, doubl
     };
 
     // ||M b|| for the relative tolerance (non-zero initial guess, preconditioned norm)
-    if (ctx->prep_b == b && restart == ctx->gm_restart) {   // already computed on the side stream (knp_gmres_prepare)
+    bool lazy_bnorm = false;
+    if (ctx->prep_b == b && restart == ctx->gm_restart && ctx->prep_conc) {
+        // concurrent form: the side-stream cycle has its own vectors and slots; it is joined after the first read-back below
+        lazy_bnorm = true;
+    } else if (ctx->prep_b == b && restart == ctx->gm_restart) {   // already computed on the side stream (knp_gmres_prepare)
         HIPCHK(hipEventSynchronize(ctx->ev_join));
         ctx->prep_b = nullptr;
         if (!ctx->h_red_dev) {
@@ -4087,10 +4225,10 @@ int knp_gmres_solve(knp_ctx* ctx, const double* b, double* x, double rtol, doubl
         KCHK(pc_apply_norm(ctx, b, ctx->d_w, cnt, &fused_norm));
         KCHK(pc_norm_read(ctx, ctx->d_w, cnt, &fused_norm));
     }
-    const double bnorm = std::sqrt(ctx->h_red[60]);
+    double bnorm = lazy_bnorm ? 0.0 : std::sqrt(ctx->h_red[60]);
     ctx->last_bnorm = bnorm;
-    if (!std::isfinite(bnorm)) { *its = 0; *rnorm = bnorm; *reason = KNP_DIVERGED_NANORINF; return KNP_OK; }
-    const double ttol = std::max(rtol * bnorm, atol);
+    if (!lazy_bnorm && !std::isfinite(bnorm)) { *its = 0; *rnorm = bnorm; *reason = KNP_DIVERGED_NANORINF; return KNP_OK; }
+    double ttol = std::max(rtol * bnorm, atol);
     const double dtol = 1e5;
     int it = 0;
     double res = 0.0, res0 = -1.0;
@@ -4103,7 +4241,39 @@ int knp_gmres_solve(knp_ctx* ctx, const double* b, double* x, double rtol, doubl
         KCHK(spmv_A(ctx, x, b, ctx->d_t, true));
         bool fused_norm = false;   // the gauge projection of r rides on the norm's reduction and on the normalisation pass
         KCHK(pc_apply_norm(ctx, ctx->d_t, ctx->d_w, cnt, &fused_norm));
+        if (lazy_bnorm && ctx->prep_deferred) {   // ||B b||: its cycle goes to the side stream now, behind the launches above
+            ctx->prep_deferred = false;
+            HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+            ctx->stream = ctx->stream2;
+            bool fn = false;
+            swap_side_ws(ctx);
+            const int rcs = pc_apply_norm(ctx, b, ctx->d_wb, cnt, &fn, true);
+            swap_side_ws(ctx);
+            ctx->stream = st;
+            KCHK(rcs);
+            HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
+        }
         KCHK(pc_norm_read(ctx, ctx->d_w, cnt, &fused_norm));
+        if (lazy_bnorm) {   // join the side stream now: its cycle ran next to the SpMV and the cycle above
+            lazy_bnorm = false;
+            HIPCHK(hipEventSynchronize(ctx->ev_join));
+            ctx->prep_b = nullptr;
+            double nb2 = ctx->h_red[SIDE_SLOT];
+            if (ctx->h_red[SIDE_SLOT + 1] != 0.0) {   // cancellation in the one-reduction norm: explicit projection and norm, in line
+                ++ctx->n_norm_fallback;
+                KCHK(pc_apply_proj(ctx, b, ctx->d_wb, cnt));
+                KCHK(dot_to_slot(ctx, ctx->d_wb, ctx->d_wb, 60));
+                KCHK(read_slots(ctx, 60, 1, ctx->seq_counter));
+                nb2 = ctx->h_red[60];
+                // ... which used the slots and vectors of the residual norm above: redo that one (rare)
+                KCHK(pc_apply_norm(ctx, ctx->d_t, ctx->d_w, cnt, &fused_norm));
+                KCHK(pc_norm_read(ctx, ctx->d_w, cnt, &fused_norm));
+            }
+            bnorm = std::sqrt(nb2);
+            ctx->last_bnorm = bnorm;
+            if (!std::isfinite(bnorm)) { *its = 0; *rnorm = bnorm; *reason = KNP_DIVERGED_NANORINF; return KNP_OK; }
+            ttol = std::max(rtol * bnorm, atol);
+        }
         const double beta = std::sqrt(ctx->h_red[60]);
         res = beta;
         if (res0 < 0) res0 = beta;
@@ -4213,6 +4383,7 @@ int knp_unpack(knp_ctx* ctx, const double* x, const knp_fields_out* f) {
     if (!x) return KNP_E_ARG;
     OutPtrs o;
     KCHK(out_ptrs(ctx, f, o, true));
+    KCHK(join_asm(ctx));   // the fields written here are what an assembly still in flight reads
     KCHK(halo_update(ctx, const_cast<double*>(x)));
     hipLaunchKernelGGL(k_unpack, dim3(nblocks(ctx->g.n_v)), dim3(NT), 0, ctx->stream, ctx->g.n_v, ctx->d_node_i, ctx->d_node_e, x, o);
     HIPCHK(hipGetLastError());
@@ -4248,6 +4419,40 @@ int knp_l2_norms(knp_ctx* ctx, const double* phi_i, const double* phi_e, double*
 }
 
 // ---- instrumentation --------------------------------------------------------------------------
+// Step timers of the host loop (the reference brackets assembly and solve with perf_counter + allreduce(MAX),
+// KNPEMIx_solver.py:402-413,434-449): a mark is one hipEventRecord on the main stream from a recycled pool -- after joining the
+// matrix assembly that may run on its own stream, so that a mark after the assembly phase covers both chains -- and
+// knp_timer_read returns the elapsed seconds between consecutive marks with ONE synchronisation.
+int knp_timer_mark(knp_ctx* ctx, int32_t join_assembly) {
+    CHECK_CTX(ctx);
+    if (join_assembly) KCHK(join_asm(ctx));
+    if (ctx->tm_used == ctx->tm_events.size()) {
+        hipEvent_t e = nullptr;
+        HIPCHK(hipEventCreate(&e));
+        ctx->tm_events.push_back(e);
+    }
+    HIPCHK(hipEventRecord(ctx->tm_events[ctx->tm_used++], ctx->stream));
+    return KNP_OK;
+}
+int knp_timer_read(knp_ctx* ctx, int32_t capacity, double* seconds, int32_t* n_intervals) {
+    CHECK_CTX(ctx);
+    if (!seconds || !n_intervals || capacity < 0) return KNP_E_ARG;
+    const size_t n = ctx->tm_used;
+    *n_intervals = 0;
+    if (n == 0) return KNP_OK;
+    if ((size_t)capacity + 1 < n) { ctx->err = "knp_timer_read: capacity below the number of marks - 1"; return KNP_E_ARG; }
+    HIPCHK(hipEventSynchronize(ctx->tm_events[n - 1]));
+    for (size_t i = 0; i + 1 < n; ++i) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, ctx->tm_events[i], ctx->tm_events[i + 1]));
+        seconds[i] = 1e-3 * (double)ms;
+    }
+    *n_intervals = (int32_t)(n - 1);
+    ctx->tm_used = 0;
+    return KNP_OK;
+}
+int knp_timer_pending(const knp_ctx* ctx) { return ctx ? (int)ctx->tm_used : 0; }
+
 int knp_profile_enable(knp_ctx* ctx, int32_t on) {
     CHECK_CTX(ctx);
     KCHK(prof_collect(ctx));
