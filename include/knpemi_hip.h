@@ -275,6 +275,11 @@ int knp_amg_set_coarse(knp_ctx* ctx, int32_t hier, int32_t n, const double* dens
  * post-smoothing as one gather per level (same operator as the unfused cycle; KNP_FUSED=0 selects the latter). */
 int knp_amg_set_level_smoothed(knp_ctx* ctx, int32_t hier, int32_t level, int32_t n_rows, const int32_t* S_rowptr, const int32_t* S_colind,
                         const double* S_vals);
+/* optional, intermediate levels (1 .. n_levels-2) of a single-GPU hierarchy whose cycle runs fused: both legs as plain products,
+ * Rt = R (I - c A Dinv) [n_coarse x n] and U = [c Dinv (2I - c A Dinv) | S] [n x (n + n_coarse)] (cgx_hip/amg.py
+ * coarse_fused_operators); replaces restriction + residual and the three-vector up-leg of those levels */
+int knp_amg_set_level_coarse_fused(knp_ctx* ctx, int32_t hier, int32_t level, int32_t Rt_rows, const int32_t* Rt_rowptr, const int32_t* Rt_colind,
+                                   const double* Rt_vals, int32_t U_rows, const int32_t* U_rowptr, const int32_t* U_colind, const double* U_vals);
 /* level 0 == the library's own P (owned block): use its pair-major storage and node kernels instead of the uploaded
  * CSR. mode: 0 off, 1 all four fields, 2 ion fields only, 3 potential only */
 int knp_amg_use_native_level0(knp_ctx* ctx, int32_t hier, int32_t mode);

@@ -91,6 +91,7 @@ SIGNATURES = {
                                                C.POINTER(C.c_double)]),
     "knp_amg_set_coarse": (C.c_int, [vp, C.c_int32, C.c_int32, f64p]),
     "knp_amg_set_level_smoothed": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, i32p, i32p, f64p]),
+    "knp_amg_set_level_coarse_fused": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, i32p, i32p, f64p, C.c_int32, i32p, i32p, f64p]),
     "knp_amg_set_node_fields": (C.c_int, [vp, C.c_int32, C.c_int32]),
     "knp_amg_use_native_level0": (C.c_int, [vp, C.c_int32, C.c_int32]),
     "knp_amg_set_precision": (C.c_int, [vp, C.c_int32]),

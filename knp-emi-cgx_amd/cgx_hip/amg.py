@@ -117,11 +117,13 @@ class Level:
     """One level: operator A, inverse diagonal, lambda_max(D^-1 A), prolongator P, restrictor R = P^T and
     S = (I - c2 D^-1 A) P with c2 = 1 / (0.6 lambda_max): prolongation followed by the post-smoothing step of the
     V(1,1) / Chebyshev-degree-1 cycle, as ONE operator (the library's fused cycle applies it in one gather)."""
-    __slots__ = ("A", "dinv", "lambda_max", "P", "R", "S", "Pt")
+    __slots__ = ("A", "dinv", "lambda_max", "P", "R", "S", "Pt", "Rt", "U")
 
-    def __init__(self, A, dinv, lambda_max, P=None, R=None, S=None):
+    def __init__(self, A, dinv, lambda_max, P=None, R=None, S=None, Rt=None, U=None):
         self.A, self.dinv, self.lambda_max, self.P, self.R, self.S = A, dinv, lambda_max, P, R, S
         self.Pt = None      # A Dinv as stored by the library on level 0 (filled by fp32_stored for checkers)
+        # levels 1 .. n-2 of the fused cycle as two plain sparse products (coarse_fused_operators)
+        self.Rt, self.U = Rt, U
 
 
 def cheby_first_coefficient(lambda_max: float) -> float:
@@ -134,6 +136,25 @@ def post_smoothed_prolongator(A, dinv, lambda_max, Pm, AP=None):
     S = (Pm - sp.diags(cheby_first_coefficient(lambda_max) * dinv) @ AP).tocsr()
     S.sort_indices()
     return S
+
+
+def coarse_fused_operators(A, dinv, lambda_max, R, S):
+    """The fused V(1,1) cycle on an INTERMEDIATE level l (neither the finest nor the coarsest), written without the level's
+    iterate and residual: with c = 1/theta, x0 = c Dinv b and r = b - A x0 = (I - c A Dinv) b,
+        down:  b_{l+1} = R r                           = Rt b,            Rt = R (I - c A Dinv)
+        up:    x = x0 + c Dinv r + S x_{l+1}           = U [b ; x_{l+1}],  U = [ c Dinv (2 I - c A Dinv) | S ]
+    i.e. ONE sparse product per leg instead of restriction + residual (two kernels at the launch floor) and a gather with three
+    extra vectors: on these levels every kernel is latency bound, so the extra entries of Rt and U cost nothing measurable."""
+    c = cheby_first_coefficient(lambda_max)
+    n = A.shape[0]
+    Dinv = sp.diags(dinv)
+    AD = (A @ Dinv).tocsr()
+    Rt = (R - c * (R @ AD)).tocsr()
+    Rt.sort_indices()
+    W = (2.0 * c * Dinv - (c * c) * (Dinv @ AD)).tocsr()
+    U = sp.hstack([W, S], format="csr")
+    U.sort_indices()
+    return Rt, U
 
 
 class Hierarchy:
@@ -301,7 +322,9 @@ def build_hierarchy(P: sp.csr_matrix, theta: float = 0.08, max_levels: int = 12,
         AP = (A @ Pm).tocsr()
         Ac = (R @ AP).tocsr()
         Ac.sort_indices()
-        levels.append(Level(A, dinv, lam, Pm, R, post_smoothed_prolongator(A, dinv, lam, Pm, AP)))
+        S_ = post_smoothed_prolongator(A, dinv, lam, Pm, AP)
+        Rt_, U_ = coarse_fused_operators(A, dinv, lam, R, S_) if levels else (None, None)      # intermediate levels only
+        levels.append(Level(A, dinv, lam, Pm, R, S_, Rt_, U_))
         A = Ac
         if sync:
             stride, fields = len(fields), tuple(range(len(fields)))      # coarse unknowns: nf * aggregate + field index
@@ -366,6 +389,17 @@ def upload(lib, ctx, check, hier: Hierarchy, pre: int = 1, post: int = 1, cheby_
                 Sv = np.ascontiguousarray(S.data, dtype=np.float64)
                 keep += [Srp, Sci, Sv]
                 check(lib.knp_amg_set_level_smoothed(ctx, index, l, S.shape[0], ip(Srp), ip(Sci), fp(Sv)))
+            Rt, U = getattr(lv, "Rt", None), getattr(lv, "U", None)
+            if Rt is not None and U is not None and l >= 1:
+                arrs = []
+                for M in (Rt, U):
+                    if not M.has_sorted_indices:
+                        M.sort_indices()
+                    arrs += [np.ascontiguousarray(M.indptr, dtype=np.int32), np.ascontiguousarray(M.indices, dtype=np.int32),
+                             np.ascontiguousarray(M.data, dtype=np.float64)]
+                keep += arrs
+                check(lib.knp_amg_set_level_coarse_fused(ctx, index, l, Rt.shape[0], ip(arrs[0]), ip(arrs[1]), fp(arrs[2]),
+                                                         U.shape[0], ip(arrs[3]), ip(arrs[4]), fp(arrs[5])))
         else:
             check(lib.knp_amg_set_level(ctx, index, l, A.shape[0], A.shape[0], ip(rp), ip(ci), fp(va), fp(dinv),
                                         float(lv.lambda_max), 0, None, None, None, None, None, None))
@@ -393,6 +427,7 @@ def fp32_stored(h: Hierarchy, coarse: bool = False) -> Hierarchy:
         l2 = copy.copy(lv)
         l2.A, l2.P, l2.R = rnd(lv.A), rnd(lv.P), rnd(lv.R)
         l2.S = rnd(getattr(lv, "S", None))
+        l2.Rt, l2.U = rnd(getattr(lv, "Rt", None)), rnd(getattr(lv, "U", None))
         out.levels.append(l2)
     if coarse and h.coarse_inv is not None:
         out.coarse_inv = h.coarse_inv.astype(np.float32).astype(np.float64)

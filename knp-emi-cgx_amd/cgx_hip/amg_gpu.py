@@ -309,7 +309,17 @@ def build_hierarchy(P, theta: float = 0.08, max_levels: int = 12, coarse_size: i
         rAP = AP.rows()
         c2 = amg.cheby_first_coefficient(lam)
         S = _from_coo(torch.cat([Pm.rows(), rAP]), torch.cat([Pm.col, AP.col]), torch.cat([Pm.val, -c2 * dinv[rAP] * AP.val]), (n, nagg))
-        levels.append(amg.Level(A_host, dinv.cpu().numpy(), lam, Pm.scipy(), R.scipy(), S.scipy()))
+        Rt_h = U_h = None
+        if levels:      # intermediate level: both legs of the fused cycle as plain products (amg.coarse_fused_operators)
+            rA, cA, vA = A.rows(), A.col, A.val
+            AD = _Csr(A.crow, A.col, vA * dinv[cA], A.shape)
+            RAD = _spgemm(R, AD)
+            Rt = _from_coo(torch.cat([R.rows(), RAD.rows()]), torch.cat([R.col, RAD.col]), torch.cat([R.val, -c2 * RAD.val]), (nagg, n))
+            dg = torch.arange(n, device=dev)
+            U = _from_coo(torch.cat([rA, dg, S.rows()]), torch.cat([cA, dg, S.col + n]),
+                          torch.cat([-(c2 * c2) * dinv[rA] * vA * dinv[cA], 2.0 * c2 * dinv, S.val]), (n, n + nagg))
+            Rt_h, U_h = Rt.scipy(), U.scipy()
+        levels.append(amg.Level(A_host, dinv.cpu().numpy(), lam, Pm.scipy(), R.scipy(), S.scipy(), Rt_h, U_h))
         A = Ac
         A_host = Ac.scipy()
         if sync:

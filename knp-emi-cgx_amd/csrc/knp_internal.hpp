@@ -145,6 +145,15 @@ struct KnpAmgLevel {
     // level 0 of a potential-only hierarchy on compact vectors [n_nodes]: node indices instead of 4*node+3
     int32_t *R_ci_c = nullptr, *S_act_rows_c = nullptr;
     double* dinv_c = nullptr;
+    // levels 1 .. n-2 of the fused cycle as two plain sparse products (knp_amg_set_level_coarse_fused; cgx_hip/amg.py
+    // coarse_fused_operators): b_{l+1} = Rt b_l on the way down, x_l = U [b_l ; x_{l+1}] on the way up.  `cat` holds b_l followed by
+    // x_{l+1} (n + n_coarse entries) so that the up-leg is an ordinary product with one input vector; `cats` = side-stream twin
+    int32_t *Rt_rp = nullptr, *Rt_ci = nullptr, *U_rp = nullptr, *U_ci = nullptr;
+    double *Rt_v = nullptr, *U_v = nullptr;
+    float *Rt_vf = nullptr, *U_vf = nullptr;
+    int Rt_lanes = 8, U_lanes = 8;
+    KnpBlockedCsr bRt, bU;
+    double *cat = nullptr, *cats = nullptr;
     KnpBlockedCsr bA, bR, bS;   // node-blocked copies (hierarchies with node_nf > 0, fp32 storage): level operator, restrictor, S
     // levels >= 1 in fused form inside the level-by-level cycle (distributed hierarchies and their replicated tails):
     // At = c A Dinv on the pattern of A (ghost columns scaled with the ghost inverse diagonal), knp_pc_setup builds it
@@ -167,6 +176,7 @@ struct KnpAmgHier {
     int l0_fused = 0;   // level 0 in fused form inside the level-by-level cycle (distributed hierarchies)
     int node_nf = 0;    // > 0: fields per node with identical patterns on every level (knp_amg_set_node_fields)
     int blocked = 0;    // the fused cycle runs on the node-blocked copies (knp_pc_setup decides)
+    int cfused = 0;     // ... and its intermediate levels as two plain products each (Rt, U)
     double *pt = nullptr, *pt_phi = nullptr;
     float *pt_f = nullptr, *pt_phi_f = nullptr;
 };

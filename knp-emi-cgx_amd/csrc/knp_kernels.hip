@@ -1426,6 +1426,99 @@ static int pick_lanes(double avg_nnz_per_row, int role = 0) {   // role 0 level 
 // ------------------------------------------------------------------------------------------
 // K5/K6: orthogonalisation and vector kernels
 // ------------------------------------------------------------------------------------------
+// ---- GMRES bookkeeping on the device (one wave): the host only reads back the residual estimate and a flag --------
+// gm layout (doubles): H [(m+1) x m, column major] | cs [m] | sn [m] | g [m+1] | y [m] | state {||w'||^2, flag, residual}
+struct GmLayout {
+    int m;
+    __host__ __device__ int H(int i, int j) const { return i + j * (m + 1); }
+    __host__ __device__ int cs() const { return (m + 1) * m; }
+    __host__ __device__ int sn() const { return cs() + m; }
+    __host__ __device__ int g() const { return sn() + m; }
+    __host__ __device__ int y() const { return g() + m + 1; }
+    __host__ __device__ int st() const { return y() + m; }
+    __host__ __device__ int size() const { return st() + 8; }
+};
+// ||w'||^2 < GM_CANCEL ||w||^2: Pythagoras has lost 8 of 16 digits, take the explicit norm.  The Arnoldi relation holds exactly
+// for ANY value used consistently as h_{j+1,j} and as the normalisation of v_{j+1}; an inexact norm only makes |v_{j+1}| differ
+// from 1 by that relative error, which perturbs the least-squares weights, not the Krylov space (well preconditioned systems
+// routinely have |w'| ~ 1e-3 |w|: a tighter guard would pay a second reduction in most of their iterations).
+static constexpr double GM_CANCEL = 1e-8;
+
+__device__ __forceinline__ void givens_body(GmLayout L, int j, int has_ns, double inv_cnt, const double* __restrict__ red, int explicit_slot,
+                                            double* __restrict__ gm, double* mirror, volatile int64_t* seq, int64_t seq_val) {
+    double* st = gm + L.st();
+    double nrm2;
+    bool cancel = false;
+    if (explicit_slot < 0) {
+        const double ww = red[j + 1 + has_ns];
+        double s = 0.0;
+        for (int i = 0; i <= j; ++i) s += red[i] * red[i];
+        if (has_ns) s += red[j + 1] * red[j + 1] * inv_cnt;   // component along the normalised null-space vector
+        nrm2 = ww - s;
+        cancel = !(nrm2 > GM_CANCEL * ww) && ww > 0.0;        // (NaNs fall through to the breakdown test below)
+    } else {
+        nrm2 = red[explicit_slot];
+    }
+    double flag = 0.0, res = 0.0;
+    if (cancel) {
+        flag = 1.0;
+        nrm2 = 1.0;
+    } else {
+        double* h = gm + L.H(0, j);
+        for (int i = 0; i <= j; ++i) h[i] = red[i];
+        h[j + 1] = sqrt(fmax(nrm2, 0.0));
+        double* cs = gm + L.cs();
+        double* sn = gm + L.sn();
+        double* g = gm + L.g();
+        for (int i = 0; i < j; ++i) {
+            const double t = cs[i] * h[i] + sn[i] * h[i + 1];
+            h[i + 1] = -sn[i] * h[i] + cs[i] * h[i + 1];
+            h[i] = t;
+        }
+        const double den = hypot(h[j], h[j + 1]);
+        if (!(den > 0.0) || !isfinite(den) || !(nrm2 == nrm2)) {
+            flag = 2.0;
+            nrm2 = 1.0;
+        } else {
+            cs[j] = h[j] / den;
+            sn[j] = h[j + 1] / den;
+            h[j] = den;
+            h[j + 1] = 0.0;
+            g[j + 1] = -sn[j] * g[j];
+            g[j] = cs[j] * g[j];
+            res = fabs(g[j + 1]);
+            if (!(nrm2 > 0.0)) nrm2 = 1.0;   // exact breakdown (w' = 0): the next basis vector is irrelevant, avoid 1/0
+        }
+    }
+    st[0] = nrm2; st[1] = flag; st[2] = res;
+    if (mirror) { mirror[0] = res; mirror[1] = flag; }
+    if (seq) {
+        __threadfence_system();
+        *seq = seq_val;
+    }
+}
+__global__ void k_givens(GmLayout L, int j, int has_ns, double inv_cnt, const double* __restrict__ red, int explicit_slot,
+                         double* __restrict__ gm, double* mirror, volatile int64_t* seq, int64_t seq_val) {
+    if (threadIdx.x != 0) return;
+    givens_body(L, j, has_ns, inv_cnt, red, explicit_slot, gm, mirror, seq, seq_val);
+}
+
+__device__ __forceinline__ void proj_norm_body(double s, double ww, double* __restrict__ red, int slot_out, double inv_count, double cancel, double* mirror,
+                                               volatile int64_t* seq, int64_t seq_val) {
+    const double nrm2 = ww - s * s * inv_count;
+    const bool bad = !(nrm2 > cancel * ww) && ww > 0.0;
+    red[slot_out] = bad ? ww : nrm2;
+    red[slot_out + 1] = bad ? 1.0 : 0.0;
+    if (mirror) { mirror[slot_out] = red[slot_out]; mirror[slot_out + 1] = red[slot_out + 1]; }
+    if (seq) {
+        __threadfence_system();
+        *seq = seq_val;
+    }
+}
+// (Measured and dropped in round 3: finishing the reduction inside k_multi_dot -- last block done, device-scope atomics, then the
+// Givens step in that block -- costs 14 us per launch on this part: the 8 XCDs have separate L2s, so every device-scope round
+// trip (write-through stores, the counter, the loads of the partial sums) goes to the memory side at 2-3 us each, more than the
+// two ~4.7 us launches it replaces (512^2: 0.649 vs 0.621 ms per step).  Kernel boundaries are the cheaper synchronisation here.)
 // partial[(i)*RED_BLOCKS + blk] = sum over this block's elements of V_i . w, i = i0 .. i0+G-1 (< m)
 // NS: additionally accumulate the sum of the potential entries of w into row `m` of partial -- the coefficient
 // of w along the (unnormalised) null-space vector, so that the gauge projection rides on the same reduction.
@@ -1455,8 +1548,9 @@ k_multi_dot(int n, int64_t ldv, int i0, int m, const double* __restrict__ V, con
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
+        if (i0 + g >= m) break;      // (uniform) the short cycles of a well preconditioned solve use 1-3 of the G accumulators
         double r = block_sum(acc[g], sm);
-        if (threadIdx.x == 0 && i0 + g < m) partial[(size_t)(i0 + g) * RED_BLOCKS + blockIdx.x] = r;
+        if (threadIdx.x == 0) partial[(size_t)(i0 + g) * RED_BLOCKS + blockIdx.x] = r;
     }
     if (NS) {
         double r = block_sum(ans, sm);
@@ -1525,7 +1619,10 @@ __global__ void __launch_bounds__(NT) k_scale_rsqrt(int n, const double* __restr
 // out = (in - mean on the potential entries) / sqrt(*nrm2), mean = *phi_sum * inv_count: the gauge projection and the normalisation
 // of the initial Krylov vector in one pass (pc_apply_norm left the vector unprojected)
 __global__ void __launch_bounds__(NT) k_scale_rsqrt_proj(int n, const double* __restrict__ in, const double* __restrict__ nrm2,
-                                                         const double* __restrict__ phi_sum, double inv_count, double* __restrict__ out) {
+                                                         const double* __restrict__ phi_sum, double inv_count, double* __restrict__ out,
+                                                         double* __restrict__ gm_g = nullptr, int m = 0) {
+    if (gm_g && blockIdx.x == 0)   // the start of a GMRES cycle: g = (beta, 0, ..., 0) (was k_gm_init)
+        for (int i = threadIdx.x; i <= m; i += NT) gm_g[i] = (i == 0) ? sqrt(*nrm2) : 0.0;
     const double inv = 1.0 / sqrt(*nrm2);
     const double mean = (*phi_sum) * inv_count;
     for (int e = blockIdx.x * NT + threadIdx.x; e < n; e += gridDim.x * NT) out[e] = ((e & 3) == 3 ? in[e] - mean : in[e]) * inv;
@@ -1535,18 +1632,8 @@ __global__ void __launch_bounds__(NT) k_scale_rsqrt_proj(int n, const double* __
 __global__ void k_proj_norm(double* __restrict__ red, int slot_s, int slot_out, double inv_count, double cancel, double* mirror,
                             volatile int64_t* seq, int64_t seq_val) {
     if (threadIdx.x != 0) return;
-    const double s = red[slot_s], ww = red[slot_s + 1];
-    const double nrm2 = ww - s * s * inv_count;
-    const bool bad = !(nrm2 > cancel * ww) && ww > 0.0;
-    red[slot_out] = bad ? ww : nrm2;
-    red[slot_out + 1] = bad ? 1.0 : 0.0;
-    if (mirror) { mirror[slot_out] = red[slot_out]; mirror[slot_out + 1] = red[slot_out + 1]; }
-    if (seq) {
-        __threadfence_system();
-        *seq = seq_val;
-    }
+    proj_norm_body(red[slot_s], red[slot_s + 1], red, slot_out, inv_count, cancel, mirror, seq, seq_val);
 }
-
 // x += sum_i y[i] V_i
 __global__ void __launch_bounds__(NT) k_lincomb(int n, int64_t ldv, int m, const double* __restrict__ V,
                                                 const double* __restrict__ y, double* __restrict__ x) {
@@ -1557,24 +1644,6 @@ __global__ void __launch_bounds__(NT) k_lincomb(int n, int64_t ldv, int m, const
     }
 }
 
-// ---- GMRES bookkeeping on the device (one wave): the host only reads back the residual estimate and a flag --------
-// gm layout (doubles): H [(m+1) x m, column major] | cs [m] | sn [m] | g [m+1] | y [m] | state {||w'||^2, flag, residual}
-struct GmLayout {
-    int m;
-    __host__ __device__ int H(int i, int j) const { return i + j * (m + 1); }
-    __host__ __device__ int cs() const { return (m + 1) * m; }
-    __host__ __device__ int sn() const { return cs() + m; }
-    __host__ __device__ int g() const { return sn() + m; }
-    __host__ __device__ int y() const { return g() + m + 1; }
-    __host__ __device__ int st() const { return y() + m; }
-    __host__ __device__ int size() const { return st() + 8; }
-};
-// ||w'||^2 < GM_CANCEL ||w||^2: Pythagoras has lost 8 of 16 digits, take the explicit norm.  The Arnoldi relation holds exactly
-// for ANY value used consistently as h_{j+1,j} and as the normalisation of v_{j+1}; an inexact norm only makes |v_{j+1}| differ
-// from 1 by that relative error, which perturbs the least-squares weights, not the Krylov space (well preconditioned systems
-// routinely have |w'| ~ 1e-3 |w|: a tighter guard would pay a second reduction in most of their iterations).
-static constexpr double GM_CANCEL = 1e-8;
-
 __global__ void k_gm_init(GmLayout L, double* __restrict__ gm, const double* __restrict__ beta2) {
     const int t = threadIdx.x;
     for (int i = t; i <= L.m; i += blockDim.x) gm[L.g() + i] = (i == 0) ? sqrt(*beta2) : 0.0;
@@ -1583,61 +1652,6 @@ __global__ void k_gm_init(GmLayout L, double* __restrict__ gm, const double* __r
 // column j of the Hessenberg matrix from the reduced values red = {h_0..h_j, [ns sum], w.w}: norm of the orthogonalised vector by
 // Pythagoras (or, explicit_slot >= 0, the explicitly reduced one), previous Givens rotations, the new rotation, the residual
 // estimate |g_{j+1}|; published to pinned host memory together with the sequence word the host spins on.
-__global__ void k_givens(GmLayout L, int j, int has_ns, double inv_cnt, const double* __restrict__ red, int explicit_slot,
-                         double* __restrict__ gm, double* mirror, volatile int64_t* seq, int64_t seq_val) {
-    if (threadIdx.x != 0) return;
-    double* st = gm + L.st();
-    double nrm2;
-    bool cancel = false;
-    if (explicit_slot < 0) {
-        const double ww = red[j + 1 + has_ns];
-        double s = 0.0;
-        for (int i = 0; i <= j; ++i) s += red[i] * red[i];
-        if (has_ns) s += red[j + 1] * red[j + 1] * inv_cnt;   // component along the normalised null-space vector
-        nrm2 = ww - s;
-        cancel = !(nrm2 > GM_CANCEL * ww) && ww > 0.0;        // (NaNs fall through to the breakdown test below)
-    } else {
-        nrm2 = red[explicit_slot];
-    }
-    double flag = 0.0, res = 0.0;
-    if (cancel) {
-        flag = 1.0;
-        nrm2 = 1.0;
-    } else {
-        double* h = gm + L.H(0, j);
-        for (int i = 0; i <= j; ++i) h[i] = red[i];
-        h[j + 1] = sqrt(fmax(nrm2, 0.0));
-        double* cs = gm + L.cs();
-        double* sn = gm + L.sn();
-        double* g = gm + L.g();
-        for (int i = 0; i < j; ++i) {
-            const double t = cs[i] * h[i] + sn[i] * h[i + 1];
-            h[i + 1] = -sn[i] * h[i] + cs[i] * h[i + 1];
-            h[i] = t;
-        }
-        const double den = hypot(h[j], h[j + 1]);
-        if (!(den > 0.0) || !isfinite(den) || !(nrm2 == nrm2)) {
-            flag = 2.0;
-            nrm2 = 1.0;
-        } else {
-            cs[j] = h[j] / den;
-            sn[j] = h[j + 1] / den;
-            h[j] = den;
-            h[j + 1] = 0.0;
-            g[j + 1] = -sn[j] * g[j];
-            g[j] = cs[j] * g[j];
-            res = fabs(g[j + 1]);
-            if (!(nrm2 > 0.0)) nrm2 = 1.0;   // exact breakdown (w' = 0): the next basis vector is irrelevant, avoid 1/0
-        }
-    }
-    st[0] = nrm2; st[1] = flag; st[2] = res;
-    if (mirror) { mirror[0] = res; mirror[1] = flag; }
-    if (seq) {
-        __threadfence_system();
-        *seq = seq_val;
-    }
-}
-
 // v_{j+1} = (w - sum_i h[i] V_i - gauge part) / ||.||  in one pass (state: {||w'||^2, flag}); with flag != 0 the vector is left
 // unnormalised (the explicit-norm fallback normalises it afterwards)
 __global__ void __launch_bounds__(NT)
@@ -1671,6 +1685,31 @@ __global__ void k_gm_solve_y(GmLayout L, int jd, double* __restrict__ gm) {
         double s = g[i];
         for (int k = i + 1; k < jd; ++k) s -= gm[L.H(i, k)] * y[k];
         y[i] = s / gm[L.H(i, i)];
+    }
+}
+
+// short cycles (jd <= 8, the usual case with a good preconditioner): every block solves the small triangular system itself from
+// a copy in LDS and applies x += V y in the same kernel -- no separate k_gm_solve_y launch; block 0 also stores y
+__global__ void __launch_bounds__(NT) k_lincomb_solve(GmLayout L, int jd, double* __restrict__ gm, int n, int64_t ldv,
+                                                      const double* __restrict__ V, double* __restrict__ x) {
+    __shared__ double sH[8 * 8], sg[8], sy[8];
+    if (threadIdx.x < jd * jd) sH[threadIdx.x] = gm[L.H(threadIdx.x % jd, threadIdx.x / jd)];   // sH[i + jd*k] = H(i, k)
+    if (threadIdx.x < jd) sg[threadIdx.x] = gm[L.g() + threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = jd - 1; i >= 0; --i) {
+            double s = sg[i];
+            for (int k = i + 1; k < jd; ++k) s -= sH[i + jd * k] * sy[k];
+            sy[i] = s / sH[i + jd * i];
+        }
+        if (blockIdx.x == 0)
+            for (int i = 0; i < jd; ++i) gm[L.y() + i] = sy[i];
+    }
+    __syncthreads();
+    for (int e = blockIdx.x * NT + threadIdx.x; e < n; e += gridDim.x * NT) {
+        double xe = x[e];
+        for (int i = 0; i < jd; ++i) xe += sy[i] * V[(int64_t)i * ldv + e];
+        x[e] = xe;
     }
 }
 
@@ -3212,13 +3251,15 @@ static void free_hier(KnpAmgHier& H) {
         dev_free(L.S_rp); dev_free(L.S_ci); dev_free(L.S_v); dev_free(L.S_vf); dev_free(L.S_act_rows); dev_free(L.S_act_rp);
         dev_free(L.R_ci_c); dev_free(L.S_act_rows_c); dev_free(L.dinv_c);
         free_blocked(L.bA); free_blocked(L.bR); free_blocked(L.bS);
+        dev_free(L.Rt_rp); dev_free(L.Rt_ci); dev_free(L.Rt_v); dev_free(L.Rt_vf); dev_free(L.U_rp); dev_free(L.U_ci); dev_free(L.U_v); dev_free(L.U_vf);
+        free_blocked(L.bRt); free_blocked(L.bU); dev_free(L.cat); dev_free(L.cats);
         dev_free(L.At_v); dev_free(L.At_vf); L.lfused = 0; L.A_nnz = 0;
         L.S_rows = L.S_n_act = 0;
         L.n = L.n_coarse = 0;
     }
     dev_free(H.cinv); dev_free(H.cinv_f);
     dev_free(H.pt); dev_free(H.pt_phi); dev_free(H.pt_f); dev_free(H.pt_phi_f);
-    H.nc = 0; H.levels = 0; H.native0 = 0; H.fused = 0; H.node_nf = 0; H.blocked = 0;
+    H.nc = 0; H.levels = 0; H.native0 = 0; H.fused = 0; H.node_nf = 0; H.blocked = 0; H.cfused = 0;
 }
 int knp_amg_reset(knp_ctx* ctx, int32_t hier, int32_t n_levels, int32_t pre, int32_t post, int32_t cheby) {
     CHECK_CTX(ctx);
@@ -3365,6 +3406,45 @@ int knp_amg_set_level_smoothed(knp_ctx* ctx, int32_t hier, int32_t level, int32_
     L.S_lanes = pick_lanes((double)nnzS / std::max(L.S_n_act > 0 ? L.S_n_act : n_rows, 1), 1);
     const int nf = ctx->hier[hier].node_nf;
     if (nf > 0 && ctx->amg_fp32) KCHK(build_blocked(ctx, nf, n_rows, level == 0 ? 4 : nf, nf, S_rp, S_ci, S_v, &L.bS));
+    return KNP_OK;
+}
+// Intermediate level of the fused cycle as two plain products (cgx_hip/amg.py coarse_fused_operators): Rt [n_coarse x n] and
+// U [n x (n + n_coarse)], CSR with sorted columns.  Optional: without them the level runs restriction + residual and the S up-leg.
+int knp_amg_set_level_coarse_fused(knp_ctx* ctx, int32_t hier, int32_t level, int32_t Rt_rows, const int32_t* Rt_rp, const int32_t* Rt_ci,
+                                   const double* Rt_v, int32_t U_rows, const int32_t* U_rp, const int32_t* U_ci, const double* U_v) {
+    CHECK_CTX(ctx);
+    if (hier < 0 || hier >= KNP_MAX_HIER || level < 1 || level >= ctx->hier[hier].levels - 1) { ctx->err = "coarse-fused operators belong to an intermediate level"; return KNP_E_ARG; }
+    KnpAmgLevel& L = ctx->hier[hier].lv[level];
+    if (!Rt_rp || !Rt_ci || !Rt_v || !U_rp || !U_ci || !U_v || L.n_coarse <= 0 || Rt_rows != L.n_coarse || U_rows != L.n || L.dist || L.n_loc != L.n) {
+        ctx->err = "coarse-fused operators: Rt is [n_coarse x n], U is [n x (n + n_coarse)], single-GPU levels only";
+        return KNP_E_ARG;
+    }
+    const int64_t nnzR = Rt_rp[Rt_rows], nnzU = U_rp[U_rows];
+    for (int64_t k = 0; k < nnzR; ++k)
+        if (Rt_ci[k] < 0 || Rt_ci[k] >= L.n) { ctx->err = "Rt column out of range"; return KNP_E_ARG; }
+    for (int64_t k = 0; k < nnzU; ++k)
+        if (U_ci[k] < 0 || U_ci[k] >= L.n + L.n_coarse) { ctx->err = "U column out of range"; return KNP_E_ARG; }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    dev_free(L.Rt_rp); dev_free(L.Rt_ci); dev_free(L.Rt_v); dev_free(L.Rt_vf); dev_free(L.U_rp); dev_free(L.U_ci); dev_free(L.U_v); dev_free(L.U_vf);
+    KCHK(dev_upload_raw(ctx, &L.Rt_rp, Rt_rp, (size_t)Rt_rows + 1));
+    KCHK(dev_upload_raw(ctx, &L.Rt_ci, Rt_ci, (size_t)nnzR));
+    KCHK(dev_upload_raw(ctx, &L.U_rp, U_rp, (size_t)U_rows + 1));
+    KCHK(dev_upload_raw(ctx, &L.U_ci, U_ci, (size_t)nnzU));
+    if (ctx->amg_fp32) {
+        std::vector<float> t(Rt_v, Rt_v + nnzR), u(U_v, U_v + nnzU);
+        KCHK(dev_upload(ctx, &L.Rt_vf, t));
+        KCHK(dev_upload(ctx, &L.U_vf, u));
+    } else {
+        KCHK(dev_upload_raw(ctx, &L.Rt_v, Rt_v, (size_t)nnzR));
+        KCHK(dev_upload_raw(ctx, &L.U_v, U_v, (size_t)nnzU));
+    }
+    L.Rt_lanes = pick_lanes((double)nnzR / std::max(Rt_rows, 1), 2);
+    L.U_lanes = pick_lanes((double)nnzU / std::max(U_rows, 1), 0);
+    const int nf = ctx->hier[hier].node_nf;
+    if (nf > 0 && ctx->amg_fp32) {
+        KCHK(build_blocked(ctx, nf, Rt_rows, nf, nf, Rt_rp, Rt_ci, Rt_v, &L.bRt, true));
+        KCHK(build_blocked(ctx, nf, U_rows, nf, nf, U_rp, U_ci, U_v, &L.bU));
+    }
     return KNP_OK;
 }
 int knp_amg_set_level_mode(knp_ctx* ctx, int32_t hier, int32_t level, int32_t distributed, int32_t repl_n) {
@@ -3685,6 +3765,20 @@ static void amg_cycle_fused(knp_ctx* ctx, KnpAmgHier& H, const double* b, double
         if (H.pt_f) launch_l0_down<float>(st, fm, std::max(2, ctx->pc_group / 2), nn, ctx->d_pair_ptr, ctx->d_pair_col, H.pt_f, b, c0, L0.r);
         else launch_l0_down<double>(st, fm, std::max(2, ctx->pc_group / 2), nn, ctx->d_pair_ptr, ctx->d_pair_col, H.pt, b, c0, L0.r);
     }
+    // where level l keeps its right-hand side / where level l's iterate goes when the intermediate levels run as plain products:
+    // b_l at the head of the level's `cat`, x_{l+1} behind it (the coarsest right-hand side and x_1 keep their own vectors)
+    auto cf_b = [&](int l) { return (l >= 1 && l <= nl - 2) ? H.lv[l].cat : H.lv[l].b; };
+    auto cf_x = [&](int l) { return l >= 2 ? H.lv[l - 1].cat + H.lv[l - 1].n : H.lv[l].x; };
+    if (H.blocked && H.cfused) {
+        const int nf = H.node_nf;
+        launch_brestrict(st, nf, 4, L0.bR, L0.r, cf_b(1), 0.0, nullptr, nullptr, nullptr);
+        for (int l = 1; l <= nl - 2; ++l) launch_brestrict(st, nf, nf, H.lv[l].bRt, cf_b(l), cf_b(l + 1), 0.0, nullptr, nullptr, nullptr);
+        if (H.cinv_f) launch_dense_matvec<float>(st, H.nc, H.cinv_f, cf_b(nl - 1), cf_x(nl - 1));
+        else launch_dense_matvec<double>(st, H.nc, H.cinv, cf_b(nl - 1), cf_x(nl - 1));
+        for (int l = nl - 2; l >= 1; --l) launch_brestrict(st, nf, nf, H.lv[l].bU, H.lv[l].cat, cf_x(l), 0.0, nullptr, nullptr, nullptr);
+        launch_blevel_up(st, nf, 4, L0.bS, cf_x(1), L0.inv_diag, b, L0.r, nullptr, c0, c0, z);
+        return;
+    }
     if (H.blocked) {   // node-blocked transfer and level operators (node-synchronised hierarchy): same cycle, one row per node
         const int nf = H.node_nf;
         for (int l = 0; l < nl - 1; ++l) {
@@ -3708,8 +3802,19 @@ static void amg_cycle_fused(knp_ctx* ctx, KnpAmgHier& H, const double* b, double
         }
         return;
     }
+    auto plain = [&](int lanes, int n_rows, const int32_t* rp, const int32_t* ci, const double* v, const float* vf, const double* x, double* y) {
+        if (vf) launch_spmv_t<0, 0, float>(st, lanes, n_rows, rp, ci, vf, x, nullptr, y);
+        else launch_spmv_t<0, 0, double>(st, lanes, n_rows, rp, ci, v, x, nullptr, y);
+    };
+    if (H.cfused) {   // scalar rows, intermediate levels as plain products
+        plain(L0.R_lanes, L0.n_coarse, L0.R_rp, phi ? L0.R_ci_c : L0.R_ci, L0.R_v, L0.R_vf, L0.r, cf_b(1));
+        for (int l = 1; l <= nl - 2; ++l) plain(H.lv[l].Rt_lanes, H.lv[l].n_coarse, H.lv[l].Rt_rp, H.lv[l].Rt_ci, H.lv[l].Rt_v, H.lv[l].Rt_vf, cf_b(l), cf_b(l + 1));
+        if (H.cinv_f) launch_dense_matvec<float>(st, H.nc, H.cinv_f, cf_b(nl - 1), cf_x(nl - 1));
+        else launch_dense_matvec<double>(st, H.nc, H.cinv, cf_b(nl - 1), cf_x(nl - 1));
+        for (int l = nl - 2; l >= 1; --l) plain(H.lv[l].U_lanes, H.lv[l].n, H.lv[l].U_rp, H.lv[l].U_ci, H.lv[l].U_v, H.lv[l].U_vf, H.lv[l].cat, cf_x(l));
+    }
     // down the hierarchy
-    for (int l = 0; l < nl - 1; ++l) {
+    for (int l = 0; l < nl - 1 && !H.cfused; ++l) {
         KnpAmgLevel& L = H.lv[l];
         KnpAmgLevel& C = H.lv[l + 1];
         const int nc = L.n_coarse;
@@ -3727,7 +3832,7 @@ static void amg_cycle_fused(knp_ctx* ctx, KnpAmgHier& H, const double* b, double
         }
     }
     // up: x_l = x_l + c2 Dinv r_l + S x_{l+1}
-    for (int l = nl - 2; l >= 0; --l) {
+    for (int l = H.cfused ? 0 : nl - 2; l >= 0; --l) {
         KnpAmgLevel& L = H.lv[l];
         KnpAmgLevel& C = H.lv[l + 1];
         const double c = cheb_c(L);
@@ -3819,6 +3924,21 @@ int knp_pc_setup(knp_ctx* ctx, int32_t kind) {
                  L.bS.n_rows * (l == 0 ? 4 : H.node_nf) == L.n;
         }
         H.blocked = ok ? 1 : 0;
+        // intermediate levels as two plain products each: every one of them must carry Rt and U (node-blocked when the cycle is)
+        const bool coff = getenv("KNP_COARSE_FUSED") && atoi(getenv("KNP_COARSE_FUSED")) == 0;
+        bool cok = !coff && H.fused && H.levels >= 3;
+        for (int l = 1; cok && l < H.levels - 1; ++l) {
+            const KnpAmgLevel& L = H.lv[l];
+            cok = L.Rt_rp && L.U_rp && (!H.blocked || (L.bRt.rp && L.bU.rp && L.bRt.n_rows * H.node_nf == L.n_coarse && L.bU.n_rows * H.node_nf == L.n));
+        }
+        H.cfused = cok ? 1 : 0;
+        for (int l = 1; cok && l < H.levels - 1; ++l) {
+            KnpAmgLevel& L = H.lv[l];
+            if (L.cat) continue;
+            const size_t nc = (size_t)L.n + (size_t)L.n_coarse;
+            HIPCHK(hipMalloc((void**)&L.cat, nc * sizeof(double)));
+            HIPCHK(hipMemsetAsync(L.cat, 0, nc * sizeof(double), ctx->stream));
+        }
     }
     for (int h = 0; h < KNP_MAX_HIER; ++h) {   // level 0 in fused form inside the level-by-level cycle (distributed hierarchies)
         KnpAmgHier& H = ctx->hier[h];
@@ -4074,6 +4194,7 @@ static int ensure_side_ws(knp_ctx* ctx) {
             const size_t n = (size_t)std::max(L.n_loc, L.n);
             if (L.xs || n == 0) continue;
             KCHK(zalloc(&L.xs, n)); KCHK(zalloc(&L.bs, n)); KCHK(zalloc(&L.rs, n)); KCHK(zalloc(&L.ds, n)); KCHK(zalloc(&L.r2s, n));
+            if (L.cat && !L.cats) KCHK(zalloc(&L.cats, (size_t)L.n + (size_t)L.n_coarse));
         }
     const size_t nl = (size_t)std::max(ctx->n_dof_local, 1);
     if (!ctx->d_t2_s) { KCHK(zalloc(&ctx->d_t2_s, nl)); KCHK(zalloc(&ctx->d_w2_s, nl)); }
@@ -4089,6 +4210,7 @@ static void swap_side_ws(knp_ctx* ctx) {   // host-side pointer swap: kernel arg
             KnpAmgLevel& L = ctx->hier[h].lv[l];
             if (!L.xs) continue;
             std::swap(L.x, L.xs); std::swap(L.b, L.bs); std::swap(L.r, L.rs); std::swap(L.d, L.ds); std::swap(L.r2, L.r2s);
+            if (L.cat && L.cats) std::swap(L.cat, L.cats);
         }
     if (ctx->d_t2 && ctx->d_t2_s) { std::swap(ctx->d_t2, ctx->d_t2_s); std::swap(ctx->d_w2, ctx->d_w2_s); }
 }
@@ -4280,12 +4402,13 @@ int knp_gmres_solve(knp_ctx* ctx, const double* b, double* x, double rtol, doubl
         if (!std::isfinite(beta)) { *reason = KNP_DIVERGED_NANORINF; break; }
         if (beta <= ttol) { *reason = (beta <= atol) ? KNP_CONVERGED_ATOL : KNP_CONVERGED_RTOL; break; }
         if (it >= max_it) { *reason = KNP_DIVERGED_ITS; break; }
-        if (fused_norm)
+        if (fused_norm) {
             hipLaunchKernelGGL(k_scale_rsqrt_proj, dim3(vec_blocks), dim3(NT), 0, st, n, ctx->d_w, ctx->d_red + 60, ctx->d_red + 62,
-                               1.0 / (double)cnt, ctx->d_V);
-        else
+                               1.0 / (double)cnt, ctx->d_V, gm + GL.g(), m);
+        } else {
             hipLaunchKernelGGL(k_scale_rsqrt, dim3(vec_blocks), dim3(NT), 0, st, n, ctx->d_w, ctx->d_red + 60, ctx->d_V);
-        hipLaunchKernelGGL(k_gm_init, dim3(1), dim3(64), 0, st, GL, gm, ctx->d_red + 60);
+            hipLaunchKernelGGL(k_gm_init, dim3(1), dim3(64), 0, st, GL, gm, ctx->d_red + 60);
+        }
         int jd = 0;
         bool stop = false;
         for (int j = 0; j < m; ++j) {
@@ -4340,8 +4463,12 @@ int knp_gmres_solve(knp_ctx* ctx, const double* b, double* x, double rtol, doubl
         }
         if (jd > 0) {
             ProfScope ps(ctx, 1);
-            hipLaunchKernelGGL(k_gm_solve_y, dim3(1), dim3(64), 0, st, GL, jd, gm);
-            hipLaunchKernelGGL(k_lincomb, dim3(vec_blocks), dim3(NT), 0, st, n, ldv, jd, ctx->d_V, gm + GL.y(), x);
+            if (jd <= 8) {
+                hipLaunchKernelGGL(k_lincomb_solve, dim3(vec_blocks), dim3(NT), 0, st, GL, jd, gm, n, ldv, ctx->d_V, x);
+            } else {
+                hipLaunchKernelGGL(k_gm_solve_y, dim3(1), dim3(64), 0, st, GL, jd, gm);
+                hipLaunchKernelGGL(k_lincomb, dim3(vec_blocks), dim3(NT), 0, st, n, ldv, jd, ctx->d_V, gm + GL.y(), x);
+            }
         }
         if (stop) break;
     }

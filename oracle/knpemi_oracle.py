@@ -1112,11 +1112,14 @@ def pc_amg_vcycle_fused(levels, coarse_inv):
         level 0 down:  r = b - c Pt b,  Pt = A Dinv           (levels[0].Pt when the test supplies the stored values)
         level l down:  x = c Dinv b ; r = b - A x
         up:            x <- x + c Dinv r + S x_coarse,  S = (I - c Dinv A) Pprol   (levels[l].S)
-    Algebraically identical to pc_amg_vcycle(levels, coarse_inv, 1, 1, 1); the rounding of operators stored in fp32 (Pt, S
-    instead of A, P) is what differs, and is what the iterate-parity tests need to reproduce."""
+    When every intermediate level carries the composite operators Rt and U (hierarchies built in round 3 and later) those levels are
+    evaluated as the library does: b_{l+1} = Rt b_l, x_l = U [b_l ; x_{l+1}].
+    Algebraically identical to pc_amg_vcycle(levels, coarse_inv, 1, 1, 1); the rounding of operators stored in fp32 (Pt, S, Rt, U
+    instead of A, P, R) is what differs, and is what the iterate-parity tests need to reproduce."""
     assert coarse_inv is not None
     nl = len(levels)
     c = [1.0 / (0.5 * (1.1 + 0.1) * lv.lambda_max) for lv in levels]
+    coarse_fused = nl >= 3 and all(getattr(levels[l], "Rt", None) is not None and getattr(levels[l], "U", None) is not None for l in range(1, nl - 1))
 
     def apply(b):
         bs, rs, xs = [b], [], []
@@ -1126,6 +1129,16 @@ def pc_amg_vcycle_fused(levels, coarse_inv):
             Pt = lv.A @ sp.diags(lv.dinv)
         rs.append(b - c[0] * (Pt @ b))
         xs.append(c[0] * lv.dinv * b)
+        if coarse_fused:
+            # intermediate levels as two plain products (knp_kernels.hip amg_cycle_fused, cgx_hip/amg.py coarse_fused_operators):
+            # b_{l+1} = Rt_l b_l on the way down, x_l = U_l [b_l ; x_{l+1}] on the way up -- no level iterate, no level residual
+            bs.append(levels[0].R @ rs[0])
+            for l in range(1, nl - 1):
+                bs.append(levels[l].Rt @ bs[l])
+            xc = coarse_inv @ bs[nl - 1]
+            for l in range(nl - 2, 0, -1):
+                xc = levels[l].U @ np.concatenate([bs[l], xc])
+            return xs[0] + c[0] * lv.dinv * rs[0] + lv.S @ xc
         for l in range(nl - 1):
             bc = levels[l].R @ rs[l]
             bs.append(bc)
