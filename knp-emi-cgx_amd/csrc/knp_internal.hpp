@@ -202,6 +202,7 @@ struct knp_ctx {
     int32_t *d_node_i = nullptr, *d_node_e = nullptr;
     int32_t *d_pair_ptr = nullptr, *d_pair_col = nullptr, *d_pair_row = nullptr;
     double *d_pair_M = nullptr, *d_pair_K = nullptr;
+    double2* d_pair_MK = nullptr;   // {M, K} per pair (SpMV with matrix-free time-invariant entries)
     int32_t *d_contrib_ptr = nullptr, *d_contrib_cell = nullptr;
     double* d_contrib_k = nullptr;
     int32_t *d_node_cell_ptr = nullptr, *d_node_cell = nullptr;

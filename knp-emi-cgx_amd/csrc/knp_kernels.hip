@@ -62,6 +62,7 @@ struct FieldPtrs {
 };
 
 static void side_discard(knp_ctx* ctx);
+static DevParams make_params(const knp_ctx* ctx);
 static int join_asm(knp_ctx* ctx);
 static void free_hier(KnpAmgHier& H);
 static inline int nblocks(int64_t n, int per = NT) { return (int)std::max<int64_t>(1, (n + per - 1) / per); }
@@ -85,6 +86,21 @@ __device__ __forceinline__ double block_sum(double v, double* sm) {
     if (threadIdx.x < (NT >> 6)) r = sm[threadIdx.x];
     if (w == 0) r = wave_sum(r);
     return r;
+}
+
+// The six time-invariant entries of a same-side node pair, (k_j,k_j) = M + dt D_j K and (phi,k_j) = dt z_j D_j K (SURVEY 3.2:
+// KNPEMIx_problem.py:586-591), from the pair's mass and stiffness constants.  ONE definition for the assembly kernels (which store
+// them in a_c for exports, vertex-block Jacobi and Dirichlet rows) and for the SpMV, which recomputes them from 16 bytes instead of
+// reading 48: the explicit fused multiply-adds make both produce the same bits.
+struct AcCoef { double a0, a1, a2, g0, g1, g2; };
+__host__ __device__ __forceinline__ AcCoef ac_coef(const DevParams& P, int side) {
+    const double D0 = side ? P.De[0] : P.Di[0], D1 = side ? P.De[1] : P.Di[1], D2 = side ? P.De[2] : P.Di[2];
+    return AcCoef{P.dt * D0, P.dt * D1, P.dt * D2, P.dt * P.z[0] * D0, P.dt * P.z[1] * D1, P.dt * P.z[2] * D2};
+}
+__device__ __forceinline__ void ac_entries(const AcCoef& C, double M, double K, double2& c0, double2& c1, double2& c2) {
+    c0 = make_double2(__fma_rn(C.a0, K, M), __fma_rn(C.a1, K, M));
+    c1 = make_double2(__fma_rn(C.a2, K, M), C.g0 * K);
+    c2 = make_double2(C.g1 * K, C.g2 * K);
 }
 
 // Part of a CSR row dot product, L lanes per row, four independent gathers in flight per lane.  These rows are short (3-40
@@ -162,14 +178,18 @@ k_assemble_nodes(int n_nodes, DevParams P, const int32_t* __restrict__ pair_ptr,
             *reinterpret_cast<double2*>(at + 4 * (size_t)p + 2) = make_double2(f2 * S2, phiphi);
             if (!TD_ONLY) {
                 const double M = pair_M[p], K = pair_K[p];
-                *reinterpret_cast<double2*>(ac + 6 * (size_t)p) = make_double2(M + P.dt * D0 * K, M + P.dt * D1 * K);              // (k,k)
-                *reinterpret_cast<double2*>(ac + 6 * (size_t)p + 2) = make_double2(M + P.dt * D2 * K, P.dt * P.z[0] * D0 * K);     // (k,k) | (phi,k)
-                *reinterpret_cast<double2*>(ac + 6 * (size_t)p + 4) = make_double2(P.dt * P.z[1] * D1 * K, P.dt * P.z[2] * D2 * K);
+                double2 c0, c1, c2;
+                ac_entries(ac_coef(P, side), M, K, c0, c1, c2);
+                *reinterpret_cast<double2*>(ac + 6 * (size_t)p) = c0;          // (k,k)
+                *reinterpret_cast<double2*>(ac + 6 * (size_t)p + 2) = c1;      // (k,k) | (phi,k)
+                *reinterpret_cast<double2*>(ac + 6 * (size_t)p + 4) = c2;      // (phi,k)
             }
         } else {
             const double M = pair_M[p], K = pair_K[p];
-            *reinterpret_cast<double2*>(at + 4 * (size_t)p) = make_double2(M + P.dt * D0 * K, M + P.dt * D1 * K);
-            *reinterpret_cast<double2*>(at + 4 * (size_t)p + 2) = make_double2(M + P.dt * D2 * K, phiphi);
+            double2 c0, c1, c2;
+            ac_entries(ac_coef(P, side), M, K, c0, c1, c2);
+            *reinterpret_cast<double2*>(at + 4 * (size_t)p) = c0;
+            *reinterpret_cast<double2*>(at + 4 * (size_t)p + 2) = make_double2(c1.x, phiphi);
         }
     };
     double T0 = 0.0, T1 = 0.0, T2 = 0.0;   // this lane's share of the sum over the node's off-diagonal pairs
@@ -248,14 +268,18 @@ k_assemble_nodes_staged(int n_nodes, DevParams P, int cmax, const int32_t* __res
             *reinterpret_cast<double2*>(at + 4 * (size_t)p + 2) = make_double2(f2 * S2, phiphi);
             if (!TD_ONLY) {
                 const double M = pair_M[p], K = pair_K[p];
-                *reinterpret_cast<double2*>(ac + 6 * (size_t)p) = make_double2(M + P.dt * D0 * K, M + P.dt * D1 * K);
-                *reinterpret_cast<double2*>(ac + 6 * (size_t)p + 2) = make_double2(M + P.dt * D2 * K, P.dt * P.z[0] * D0 * K);
-                *reinterpret_cast<double2*>(ac + 6 * (size_t)p + 4) = make_double2(P.dt * P.z[1] * D1 * K, P.dt * P.z[2] * D2 * K);
+                double2 c0, c1, c2;
+                ac_entries(ac_coef(P, side), M, K, c0, c1, c2);
+                *reinterpret_cast<double2*>(ac + 6 * (size_t)p) = c0;          // (k,k)
+                *reinterpret_cast<double2*>(ac + 6 * (size_t)p + 2) = c1;      // (k,k) | (phi,k)
+                *reinterpret_cast<double2*>(ac + 6 * (size_t)p + 4) = c2;      // (phi,k)
             }
         } else {
             const double M = pair_M[p], K = pair_K[p];
-            *reinterpret_cast<double2*>(at + 4 * (size_t)p) = make_double2(M + P.dt * D0 * K, M + P.dt * D1 * K);
-            *reinterpret_cast<double2*>(at + 4 * (size_t)p + 2) = make_double2(M + P.dt * D2 * K, phiphi);
+            double2 c0, c1, c2;
+            ac_entries(ac_coef(P, side), M, K, c0, c1, c2);
+            *reinterpret_cast<double2*>(at + 4 * (size_t)p) = c0;
+            *reinterpret_cast<double2*>(at + 4 * (size_t)p + 2) = make_double2(c1.x, phiphi);
         }
     };
     double T0 = 0.0, T1 = 0.0, T2 = 0.0;
@@ -336,14 +360,18 @@ k_assemble_nodes_tr(int n_nodes, DevParams P, int cmax, const int32_t* __restric
             *reinterpret_cast<double2*>(at + 4 * (size_t)p + 2) = make_double2(f2 * S2, phiphi);
             if (!TD_ONLY) {
                 const double M = pair_M[p], K = pair_K[p];
-                *reinterpret_cast<double2*>(ac + 6 * (size_t)p) = make_double2(M + P.dt * D0 * K, M + P.dt * D1 * K);
-                *reinterpret_cast<double2*>(ac + 6 * (size_t)p + 2) = make_double2(M + P.dt * D2 * K, P.dt * P.z[0] * D0 * K);
-                *reinterpret_cast<double2*>(ac + 6 * (size_t)p + 4) = make_double2(P.dt * P.z[1] * D1 * K, P.dt * P.z[2] * D2 * K);
+                double2 c0, c1, c2;
+                ac_entries(ac_coef(P, side), M, K, c0, c1, c2);
+                *reinterpret_cast<double2*>(ac + 6 * (size_t)p) = c0;          // (k,k)
+                *reinterpret_cast<double2*>(ac + 6 * (size_t)p + 2) = c1;      // (k,k) | (phi,k)
+                *reinterpret_cast<double2*>(ac + 6 * (size_t)p + 4) = c2;      // (phi,k)
             }
         } else {
             const double M = pair_M[p], K = pair_K[p];
-            *reinterpret_cast<double2*>(at + 4 * (size_t)p) = make_double2(M + P.dt * D0 * K, M + P.dt * D1 * K);
-            *reinterpret_cast<double2*>(at + 4 * (size_t)p + 2) = make_double2(M + P.dt * D2 * K, phiphi);
+            double2 c0, c1, c2;
+            ac_entries(ac_coef(P, side), M, K, c0, c1, c2);
+            *reinterpret_cast<double2*>(at + 4 * (size_t)p) = c0;
+            *reinterpret_cast<double2*>(at + 4 * (size_t)p + 2) = make_double2(c1.x, phiphi);
         }
     };
     double T0 = 0.0, T1 = 0.0, T2 = 0.0;
@@ -582,10 +610,14 @@ k_spmv(int n_rows, const int32_t* __restrict__ rp, const int32_t* __restrict__ c
 // coupling to the other side's potentials (a_x, 32 B + a 4-byte column per membrane neighbour).
 // `nodes` (optional) lists the nodes to process: interior / boundary split of the multi-GPU path.
 // ------------------------------------------------------------------------------------------
-template <int G, int MODE>
+// MF ("matrix-free constants", the default without Dirichlet rows): the six time-invariant entries of a pair are not read (48 B) but
+// recomputed from its mass and stiffness constants (16 B, `mk`) with ac_entries -- bit-identical to the stored a_c, 35 % less
+// traffic per pair (52 instead of 84 bytes with the neighbour index).
+template <int G, int MODE, bool MF>
 __global__ void __launch_bounds__(NT)
 k_spmv_node(int n_list, const int32_t* __restrict__ nodes, const int32_t* __restrict__ pair_ptr, const int32_t* __restrict__ pair_col,
-            const double* __restrict__ ac, const double* __restrict__ at, const int32_t* __restrict__ node_gv,
+            const double* __restrict__ ac, const double2* __restrict__ mk, AcCoef coef_i, AcCoef coef_e,
+            const double* __restrict__ at, const int32_t* __restrict__ node_gv,
             const uint8_t* __restrict__ node_side, const int32_t* __restrict__ gptr, const int32_t* __restrict__ gx_i,
             const int32_t* __restrict__ gx_e, const double* __restrict__ ax,
             const double* __restrict__ x, const double* __restrict__ b, double* __restrict__ y) {
@@ -597,13 +629,20 @@ k_spmv_node(int n_list, const int32_t* __restrict__ nodes, const int32_t* __rest
         node = nodes ? nodes[i] : i;
         const int p0 = pair_ptr[node];
         const int p1 = pair_ptr[node + 1];
+        const AcCoef C = (MF && node_side[node]) ? coef_e : coef_i;      // pairs join nodes of the same side
         for (int p = p0 + lane; p < p1; p += G) {
             const int nb = pair_col[p];
             const double2 xa = *reinterpret_cast<const double2*>(x + 4 * (size_t)nb);
             const double2 xb = *reinterpret_cast<const double2*>(x + 4 * (size_t)nb + 2);
-            const double2 c0 = *reinterpret_cast<const double2*>(ac + 6 * (size_t)p);        // kk0 kk1
-            const double2 c1 = *reinterpret_cast<const double2*>(ac + 6 * (size_t)p + 2);    // kk2 phik0
-            const double2 c2 = *reinterpret_cast<const double2*>(ac + 6 * (size_t)p + 4);    // phik1 phik2
+            double2 c0, c1, c2;                                                                  // kk0 kk1 | kk2 phik0 | phik1 phik2
+            if (MF) {
+                const double2 m = mk[p];
+                ac_entries(C, m.x, m.y, c0, c1, c2);
+            } else {
+                c0 = *reinterpret_cast<const double2*>(ac + 6 * (size_t)p);
+                c1 = *reinterpret_cast<const double2*>(ac + 6 * (size_t)p + 2);
+                c2 = *reinterpret_cast<const double2*>(ac + 6 * (size_t)p + 4);
+            }
             const double2 t0 = *reinterpret_cast<const double2*>(at + 4 * (size_t)p);        // kphi0 kphi1
             const double2 t1 = *reinterpret_cast<const double2*>(at + 4 * (size_t)p + 2);    // kphi2 phiphi
             y0 += c0.x * xa.x + t0.x * xb.y;
@@ -655,10 +694,16 @@ template <int MODE>
 static void launch_spmv_node(knp_ctx* ctx, int n_list, const int32_t* nodes, const double* x, const double* b, double* y,
                              hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr) {
     if (n_list <= 0) return;
-#define KNP_SPMV_NODE(GG)                                                                                                              \
-    hipExtLaunchKernelGGL((k_spmv_node<GG, MODE>), dim3(nblocks((int64_t)n_list * GG)), dim3(NT), 0, ctx->stream, ev_a, ev_b, 0, n_list, nodes, \
-                          ctx->d_pair_ptr, ctx->d_pair_col, ctx->d_ac, ctx->d_at, ctx->d_node_gv, ctx->d_node_side, ctx->d_gptr, ctx->d_gx_i,     \
+    // Dirichlet rows rewrite stored entries of a_c (identity rows): those contexts read the stored values
+    static const bool mf_off = getenv("KNP_SPMV_MF") && atoi(getenv("KNP_SPMV_MF")) == 0;
+    const bool mf = !mf_off && ctx->n_bc == 0 && ctx->d_pair_MK != nullptr;
+    const DevParams P = make_params(ctx);
+    const AcCoef ci = ac_coef(P, 0), ce = ac_coef(P, 1);
+#define KNP_SPMV_NODE2(GG, MFF)                                                                                                        \
+    hipExtLaunchKernelGGL((k_spmv_node<GG, MODE, MFF>), dim3(nblocks((int64_t)n_list * GG)), dim3(NT), 0, ctx->stream, ev_a, ev_b, 0, n_list, nodes, \
+                          ctx->d_pair_ptr, ctx->d_pair_col, ctx->d_ac, ctx->d_pair_MK, ci, ce, ctx->d_at, ctx->d_node_gv, ctx->d_node_side, ctx->d_gptr, ctx->d_gx_i, \
                           ctx->d_gx_e, ctx->d_ax, x, b, y)
+#define KNP_SPMV_NODE(GG) do { if (mf) KNP_SPMV_NODE2(GG, true); else KNP_SPMV_NODE2(GG, false); } while (0)
     switch (ctx->spmv_group) {
         case 4: KNP_SPMV_NODE(4); break;
         case 8: KNP_SPMV_NODE(8); break;
@@ -666,6 +711,7 @@ static void launch_spmv_node(knp_ctx* ctx, int n_list, const int32_t* nodes, con
         default: KNP_SPMV_NODE(32); break;
     }
 #undef KNP_SPMV_NODE
+#undef KNP_SPMV_NODE2
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2359,6 +2405,11 @@ int knp_create(knp_ctx** out, const knp_mesh_desc* mesh) {
     KCHK(dev_upload(ctx, &ctx->d_pair_row, g.pair_row));
     KCHK(dev_upload(ctx, &ctx->d_pair_M, g.pair_M));
     KCHK(dev_upload(ctx, &ctx->d_pair_K, g.pair_K));
+    {   // {M, K} interleaved per pair: what the SpMV on A reads instead of the six stored time-invariant entries
+        std::vector<double2> mk(g.pair_M.size());
+        for (size_t i = 0; i < mk.size(); ++i) mk[i] = make_double2(g.pair_M[i], g.pair_K[i]);
+        KCHK(dev_upload(ctx, &ctx->d_pair_MK, mk));
+    }
     KCHK(dev_upload(ctx, &ctx->d_contrib_ptr, g.contrib_ptr));
 
     KCHK(dev_upload(ctx, &ctx->d_contrib_k, g.contrib_k));
@@ -2490,7 +2541,7 @@ int knp_destroy(knp_ctx* ctx) {
     dev_free(ctx->d_cells); dev_free(ctx->d_cell_side); dev_free(ctx->d_coords);
     dev_free(ctx->d_node_vertex); dev_free(ctx->d_node_side); dev_free(ctx->d_node_i); dev_free(ctx->d_node_e);
     dev_free(ctx->d_pair_ptr); dev_free(ctx->d_pair_col); dev_free(ctx->d_pair_row);
-    dev_free(ctx->d_pair_M); dev_free(ctx->d_pair_K);
+    dev_free(ctx->d_pair_M); dev_free(ctx->d_pair_K); dev_free(ctx->d_pair_MK);
     dev_free(ctx->d_contrib_ptr); dev_free(ctx->d_contrib_cell); dev_free(ctx->d_contrib_k);
     dev_free(ctx->d_node_cell_ptr); dev_free(ctx->d_node_cell); dev_free(ctx->d_contrib_slot);
     dev_free(ctx->d_tc_meta); dev_free(ctx->d_tc_k); dev_free(ctx->d_tc_slot);
