@@ -1561,6 +1561,38 @@ __device__ __forceinline__ void proj_norm_body(double s, double ww, double* __re
         *seq = seq_val;
     }
 }
+// ONE GPU (no all-reduce between the partial sums and their use): the second reduction stage and the scalar bookkeeping in ONE
+// single-block kernel instead of k_reduce_partials + k_givens (or + k_proj_norm) -- one launch at the ~4.5 us floor less per GMRES
+// iteration and per norm.  One wave per row, 16 partial sums per lane, fixed order: deterministic.
+//   mode 1: Givens step of iteration j on red[slot0 .. slot0 + nred)      mode 2: gauge-projected norm from {s, w.w}
+__global__ void __launch_bounds__(NT)
+k_reduce_fin(int mode, int nb, int nred, const double* __restrict__ partial, double* __restrict__ red, int slot0, GmLayout L, int j, int has_ns,
+             double inv_cnt, double* __restrict__ gm, int slot_out, double cancel, double* mirror, volatile int64_t* seq, int64_t seq_val) {
+    __shared__ double s_red[RED_SLOTS];
+    static_assert(RED_BLOCKS == 1024, "k_reduce_fin: 16 partial sums per lane");
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int row = wave; row < nred; row += NT / 64) {
+        double v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int b = lane + 64 * k;
+            v[k] = b < nb ? partial[(size_t)row * RED_BLOCKS + b] : 0.0;
+        }
+        double a = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a += v[k];
+        a = wave_sum(a);
+        if (lane == 0) s_red[row] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < nred) red[slot0 + threadIdx.x] = s_red[threadIdx.x];
+    if (threadIdx.x == 0) {
+        if (mode == 1) givens_body(L, j, has_ns, inv_cnt, s_red, -1, gm, mirror, seq, seq_val);
+        else proj_norm_body(s_red[0], s_red[1], red, slot_out, inv_cnt, cancel, mirror, seq, seq_val);
+    }
+}
+static bool fin_ok(const knp_ctx* ctx);
+
 // (Measured and dropped in round 3: finishing the reduction inside k_multi_dot -- last block done, device-scope atomics, then the
 // Givens step in that block -- costs 14 us per launch on this part: the 8 XCDs have separate L2s, so every device-scope round
 // trip (write-through stores, the counter, the loads of the partial sums) goes to the memory side at 2-3 us each, more than the
@@ -4177,6 +4209,11 @@ static bool exchanges_all_native(const knp_ctx* ctx) {
 // together and |z - ns (ns.z)|^2 = z.z - s^2/cnt (k_proj_norm; slot 60 = the norm, 61 = its cancellation flag, 62 = s).  z itself is
 // left UNPROJECTED (*fused = true): the caller subtracts the mean when it normalises (k_scale_rsqrt_proj) or does not need z at
 // all (||B b||).  Without a null space: the plain sequence, *fused = false.
+// contexts without an exchange between the partial sums and their use: the reduction finishes in one single-block kernel
+static bool fin_ok(const knp_ctx* ctx) {
+    static const bool off = getenv("KNP_FIN") && atoi(getenv("KNP_FIN")) == 0;
+    return !off && !ctx->allreduce && ctx->p2p_red < 0;
+}
 static bool fused_norm_possible(const knp_ctx* ctx, int64_t cnt) {
     static const bool off = getenv("KNP_NO_FUSED_NORM") != nullptr;
     return ctx->ns_on && cnt > 0 && !off && ctx->defl_m == 0;
@@ -4192,10 +4229,9 @@ static int pc_apply_norm(knp_ctx* ctx, const double* r, double* z, int64_t cnt, 
         const int nb = ctx->n_red_blocks;
         hipLaunchKernelGGL((k_multi_dot<8, true, true>), dim3(nb), dim3(NT), 0, ctx->stream, ctx->n_dof_owned, (int64_t)ctx->n_dof_local, 0, 0,
                            ctx->d_V, z, ctx->d_partial_s);
-        hipLaunchKernelGGL(k_reduce_partials, dim3(2), dim3(NT), 0, ctx->stream, nb, ctx->d_partial_s, ctx->d_red, SIDE_SLOT + 2, (double*)nullptr);
         ++ctx->n_allreduce;
-        hipLaunchKernelGGL(k_proj_norm, dim3(1), dim3(64), 0, ctx->stream, ctx->d_red, SIDE_SLOT + 2, SIDE_SLOT, 1.0 / (double)cnt, GM_CANCEL, ctx->mirror(),
-                           (volatile int64_t*)nullptr, (int64_t)0);
+        hipLaunchKernelGGL(k_reduce_fin, dim3(1), dim3(NT), 0, ctx->stream, 2, nb, 2, ctx->d_partial_s, ctx->d_red, SIDE_SLOT + 2, GmLayout{1}, 0, 0,
+                           1.0 / (double)cnt, (double*)nullptr, SIDE_SLOT, GM_CANCEL, ctx->mirror(), (volatile int64_t*)nullptr, (int64_t)0);
         HIPCHK(hipGetLastError());
         return KNP_OK;
     }
@@ -4210,6 +4246,13 @@ static int pc_apply_norm(knp_ctx* ctx, const double* r, double* z, int64_t cnt, 
     const int nb = ctx->n_red_blocks;
     hipLaunchKernelGGL((k_multi_dot<8, true, true>), dim3(nb), dim3(NT), 0, ctx->stream, ctx->n_dof_owned, (int64_t)ctx->n_dof_local, 0, 0,
                        ctx->d_V, z, ctx->d_partial);
+    if (fin_ok(ctx)) {
+        ++ctx->n_allreduce;
+        hipLaunchKernelGGL(k_reduce_fin, dim3(1), dim3(NT), 0, ctx->stream, 2, nb, 2, ctx->d_partial, ctx->d_red, 62, GmLayout{1}, 0, 0, 1.0 / (double)cnt,
+                           (double*)nullptr, 60, GM_CANCEL, ctx->mirror(), ctx->mirror() ? ctx->h_seq_dev : nullptr, ++ctx->seq_counter);
+        HIPCHK(hipGetLastError());
+        return KNP_OK;
+    }
     hipLaunchKernelGGL(k_reduce_partials, dim3(2), dim3(NT), 0, ctx->stream, nb, ctx->d_partial, ctx->d_red, 62, (double*)nullptr);
     KCHK(allreduce_slots(ctx, 62, 2));
     hipLaunchKernelGGL(k_proj_norm, dim3(1), dim3(64), 0, ctx->stream, ctx->d_red, 62, 60, 1.0 / (double)cnt, GM_CANCEL, ctx->mirror(),
@@ -4484,10 +4527,16 @@ int knp_gmres_solve(knp_ctx* ctx, const double* b, double* x, double rtol, doubl
                         hipLaunchKernelGGL((k_multi_dot<8, false, false>), dim3(nb), dim3(NT), 0, st, n, ldv, i0, j + 1, ctx->d_V, ctx->d_w, ctx->d_partial);
                 }
                 const int nred = j + 2 + nsi;
-                hipLaunchKernelGGL(k_reduce_partials, dim3(nred), dim3(NT), 0, st, nb, ctx->d_partial, ctx->d_red, 0, (double*)nullptr);
-                KCHK(allreduce_slots(ctx, 0, nred));
-                hipLaunchKernelGGL(k_givens, dim3(1), dim3(64), 0, st, GL, j, nsi, ns ? 1.0 / (double)cnt : 0.0, ctx->d_red, -1, gm,
-                                   ctx->mirror() ? ctx->h_red_dev + GM_RES : nullptr, ctx->mirror() ? ctx->h_seq_dev : nullptr, ++ctx->seq_counter);
+                if (fin_ok(ctx)) {   // one GPU: second reduction stage + Givens step in one single-block kernel
+                    ++ctx->n_allreduce;
+                    hipLaunchKernelGGL(k_reduce_fin, dim3(1), dim3(NT), 0, st, 1, nb, nred, ctx->d_partial, ctx->d_red, 0, GL, j, nsi, ns ? 1.0 / (double)cnt : 0.0, gm,
+                                       0, 0.0, ctx->mirror() ? ctx->h_red_dev + GM_RES : nullptr, ctx->mirror() ? ctx->h_seq_dev : nullptr, ++ctx->seq_counter);
+                } else {
+                    hipLaunchKernelGGL(k_reduce_partials, dim3(nred), dim3(NT), 0, st, nb, ctx->d_partial, ctx->d_red, 0, (double*)nullptr);
+                    KCHK(allreduce_slots(ctx, 0, nred));
+                    hipLaunchKernelGGL(k_givens, dim3(1), dim3(64), 0, st, GL, j, nsi, ns ? 1.0 / (double)cnt : 0.0, ctx->d_red, -1, gm,
+                                       ctx->mirror() ? ctx->h_red_dev + GM_RES : nullptr, ctx->mirror() ? ctx->h_seq_dev : nullptr, ++ctx->seq_counter);
+                }
                 hipLaunchKernelGGL(k_update_scale, dim3(nb), dim3(NT), 0, st, n, ldv, j + 1, ctx->d_V, ctx->d_red, ctx->d_w, gm + GL.st(),
                                    ns ? 1.0 / (double)cnt : 0.0, vn);
                 HIPCHK(hipGetLastError());
