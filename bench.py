@@ -333,6 +333,7 @@ def main_case(args, world, rank, dist, torch):
         for k in ("amg_pre", "amg_post", "amg_cheby_degree", "amg_theta", "amg_coarse_size", "amg_fp32", "amg_node_sync"):
             setattr(sp_, k, getattr(solver, k))
         sp_.fused = bool(be.stats()["fused"])
+        sp_.coupled_phi = bool(getattr(solver, "_coupled_phi", False))
         info = {"case": {"kind": case["kind"], "N": case["N"], "pc": case["pc"]}, "solver": sp_, "snap": run["snap"]}
     return out, fail, info
 
@@ -440,7 +441,8 @@ def cpu_baseline(case, args, solver, snap):
             if pc == "btcc":
                 built["k"] = rnd(amg.build_hierarchy(amg.restrict_to_fields(P, (0, 1, 2)), theta=solver.amg_theta, coarse_size=solver.amg_coarse_size,
                                                      node_fields=(4, (0, 1, 2)) if solver.amg_node_sync else None), coarse=fused)
-                built["p"] = rnd(amg.build_hierarchy(amg.restrict_to_fields(P, (3,)), theta=solver.amg_theta, coarse_size=solver.amg_coarse_size))
+                built["p"] = rnd(amg.build_hierarchy(o.potential_block_of_A() if solver.coupled_phi else amg.restrict_to_fields(P, (3,)),
+                                                     theta=solver.amg_theta, coarse_size=solver.amg_coarse_size), level0_uploaded=solver.coupled_phi)
             else:
                 built["h"] = rnd(amg.build_hierarchy(P, theta=solver.amg_theta, coarse_size=solver.amg_coarse_size,
                                                      node_fields=(4, (0, 1, 2, 3)) if solver.amg_node_sync else None))

@@ -140,7 +140,8 @@ typedef struct {
 enum {
     KNP_SZ_N_NODES = 0, KNP_SZ_N_NODES_OWNED = 1, KNP_SZ_N_DOF_LOCAL = 2, KNP_SZ_N_DOF_OWNED = 3,
     KNP_SZ_NNZ = 4, KNP_SZ_N_PAIRS = 5, KNP_SZ_N_CONTRIB = 6, KNP_SZ_N_GAMMA_VERTS = 7,
-    KNP_SZ_N_GAMMA_PAIRS = 8, KNP_SZ_NNZ_P = 9, KNP_SZ_N_PHI_OWNED = 10, KNP_SZ_COUNT = 16
+    KNP_SZ_N_GAMMA_PAIRS = 8, KNP_SZ_NNZ_P = 9, KNP_SZ_N_PHI_OWNED = 10,
+    KNP_SZ_NNZ_P_PHI = 11 /* entries of knp_get_precond_phi_csr */, KNP_SZ_COUNT = 16
 };
 
 /* communication hooks (multi-GPU); both receive DEVICE pointers */
@@ -230,6 +231,11 @@ int knp_assemble_matrix(knp_ctx* ctx, const knp_fields* fields);
 int knp_assemble_matrix_async(knp_ctx* ctx, const knp_fields* fields);
 int knp_assemble_rhs(knp_ctx* ctx, const knp_fields* fields, double* b /* device [n_dof_local] */);
 int knp_assemble_precond(knp_ctx* ctx, const knp_fields* fields);
+/* form of the potential block of P: 0 the reference's (- (C_M/F) M_Gamma per side, sides uncoupled, KNPEMIx_problem.py:735-738),
+ * 1 the potential block of A at assembly time (+ (C_M/F) M_Gamma and the phi_i-phi_e coupling, :637-638).  Before knp_assemble_precond. */
+int knp_pc_set_coupled_potential(knp_ctx* ctx, int32_t on);
+/* the potential block of P on node-indexed rows / columns: CSR [n_nodes_owned + 1], [KNP_SZ_NNZ_P_PHI] x 2, columns unsorted */
+int knp_get_precond_phi_csr(const knp_ctx* ctx, int32_t* rowptr, int32_t* colind, double* vals);
 
 /* ---- linear algebra ---- */
 int knp_spmv(knp_ctx* ctx, const double* x, double* y); /* y(owned) = A x ; calls the halo hook first */
@@ -281,7 +287,8 @@ int knp_amg_set_level_smoothed(knp_ctx* ctx, int32_t hier, int32_t level, int32_
 int knp_amg_set_level_coarse_fused(knp_ctx* ctx, int32_t hier, int32_t level, int32_t Rt_rows, const int32_t* Rt_rowptr, const int32_t* Rt_colind,
                                    const double* Rt_vals, int32_t U_rows, const int32_t* U_rowptr, const int32_t* U_colind, const double* U_vals);
 /* level 0 == the library's own P (owned block): use its pair-major storage and node kernels instead of the uploaded
- * CSR. mode: 0 off, 1 all four fields, 2 ion fields only, 3 potential only */
+ * CSR. mode: 0 off, 1 all four fields, 2 ion fields only, 3 potential only, 4 potential only on node-indexed vectors with the
+ * UPLOADED level-0 operator (one GPU; the operator may couple the two sides of the membrane, knp_pc_set_coupled_potential) */
 int knp_amg_use_native_level0(knp_ctx* ctx, int32_t hier, int32_t mode);
 /* mixed-precision preconditioner: level operators, transfer operators and P on level 0 are STORED in fp32
  * (converted on load); every vector, the dense coarse inverse, the system matrix and the Krylov process stay fp64.

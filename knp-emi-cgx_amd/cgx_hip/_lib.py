@@ -16,7 +16,7 @@ KNP_MAX_AUX = 8
 KNP_MAX_PROG_REGS = 48
 KNP_SZ_COUNT = 16
 (SZ_N_NODES, SZ_N_NODES_OWNED, SZ_N_DOF_LOCAL, SZ_N_DOF_OWNED, SZ_NNZ, SZ_N_PAIRS, SZ_N_CONTRIB,
- SZ_N_GAMMA_VERTS, SZ_N_GAMMA_PAIRS, SZ_NNZ_P, SZ_N_PHI_OWNED) = range(11)
+ SZ_N_GAMMA_VERTS, SZ_N_GAMMA_PAIRS, SZ_NNZ_P, SZ_N_PHI_OWNED, SZ_NNZ_P_PHI) = range(12)
 
 PC_NONE, PC_VBJACOBI, PC_AMG, PC_AMG_BT, PC_AMG_LT = 0, 1, 2, 3, 4
 
@@ -76,6 +76,8 @@ SIGNATURES = {
     "knp_assemble_matrix_async": (C.c_int, [vp, C.POINTER(Fields)]),
     "knp_assemble_rhs": (C.c_int, [vp, C.POINTER(Fields), vp]),
     "knp_assemble_precond": (C.c_int, [vp, C.POINTER(Fields)]),
+    "knp_pc_set_coupled_potential": (C.c_int, [vp, C.c_int32]),
+    "knp_get_precond_phi_csr": (C.c_int, [vp, i32p, i32p, f64p]),
     "knp_spmv": (C.c_int, [vp, vp, vp]),
     "knp_set_nullspace": (C.c_int, [vp, C.c_int32]),
     "knp_project_nullspace": (C.c_int, [vp, vp]),

@@ -193,6 +193,7 @@ def _replicate_pattern(Sn: sp.csr_matrix, stride: int, fields, n_dof: int) -> sp
 
 
 DENSE_LIMIT = 6000      # largest coarsest level that gets a dense pseudo-inverse
+ELIMINATION_LEVEL_MAX = 200000   # levels up to this many coupled unknowns are searched for an independent set to eliminate exactly
 
 
 def _decoupled_rows(A: sp.csr_matrix, diag: np.ndarray) -> np.ndarray:
@@ -203,9 +204,83 @@ def _decoupled_rows(A: sp.csr_matrix, diag: np.ndarray) -> np.ndarray:
     return (diag != 0.0) & (cnt == 0)
 
 
+def low_degree_independent_set(A: sp.csr_matrix, active: np.ndarray, seed: int = 0) -> np.ndarray:
+    """Maximal independent set of the graph of A restricted to the ``active`` rows, built greedily from the rows of LOWEST degree
+    (Luby rounds with priority = -degree, ties broken by a fixed pseudo-random permutation: deterministic for a given seed).  In
+    the potential block of a tissue mesh, once every biological cell has collapsed into ONE unknown, those unknowns couple only
+    to extracellular aggregates, never to each other: they are the low-degree rows and form the independent set by themselves."""
+    n = A.shape[0]
+    coo = A.tocoo()
+    m = (coo.row != coo.col) & (coo.data != 0.0) & active[coo.row] & active[coo.col]
+    G = sp.csr_matrix((np.ones(int(m.sum())), (coo.row[m], coo.col[m])), shape=(n, n))
+    G = ((G + G.T) > 0).astype(np.float64).tocsr()
+    deg = np.diff(G.indptr).astype(np.float64)
+    perm = np.random.default_rng(seed).permutation(n).astype(np.float64)
+    prio = (deg.max() + 1.0 - deg) * (n + 1.0) + perm + 1.0          # larger = earlier; unique
+    state = np.where(active, 0, 2).astype(np.int8)                   # 0 undecided, 1 in the set, 2 out
+    for _ in range(200):
+        und = state == 0
+        if not und.any():
+            break
+        w = np.where(und, prio, 0.0)
+        nbmax = _row_max(G.indptr, w[G.indices], 0.0)
+        new = und & (w > nbmax)
+        state[new] = 1
+        hit = _row_max(G.indptr, new.astype(np.float64)[G.indices], 0.0) > 0
+        state[(state == 0) & hit] = 2
+    return state == 1
+
+
+def elimination_level(A: sp.csr_matrix, diag: np.ndarray, F: np.ndarray, C: np.ndarray, lam: float):
+    """Exact elimination of an independent set F as one level of the cycle: prolongator [-D_F^-1 A_FC ; I_C] (the ideal
+    interpolation: the Galerkin operator is the Schur complement on C) and a smoother that solves the F rows exactly and leaves
+    the C rows alone (inverse diagonal 1/(c d) on F so that the damped-Jacobi step c Dinv r is exact there, 0 on C).  With these the
+    V(1,1) step on this level is a direct block factorisation, whatever the degree of the eliminated unknowns.
+    Returns (dinv, prolongator)."""
+    n = A.shape[0]
+    c = cheby_first_coefficient(lam)
+    dinv = np.zeros(n)
+    dinv[F] = 1.0 / (c * diag[F])
+    iC = np.nonzero(C)[0]
+    iF = np.nonzero(F)[0]
+    colmap = np.full(n, -1, dtype=np.int64)
+    colmap[iC] = np.arange(iC.size)
+    AFC = A[iF][:, iC].tocoo()
+    rows = np.concatenate([iF[AFC.row], iC])
+    cols = np.concatenate([AFC.col, np.arange(iC.size)])
+    vals = np.concatenate([-AFC.data / diag[iF[AFC.row]], np.ones(iC.size)])
+    Pm = sp.csr_matrix((vals, (rows, cols)), shape=(n, iC.size))
+    Pm.sort_indices()
+    return dinv, Pm
+
+
+def try_elimination_level(A, diag, dinv, active, iso, lam, coarse_size, n_levels_so_far):
+    """The elimination level of ``build_hierarchy`` (shared by the host and the device builder, which hands its small levels to
+    SciPy for this): (Level, Galerkin operator) when the coupled unknowns of this level contain an independent set whose
+    elimination leaves at most ``coarse_size`` unknowns, else None."""
+    core = active & ~iso
+    F = low_degree_independent_set(A, core, seed=n_levels_so_far)
+    C = core & ~F
+    nC, nF = int(C.sum()), int(F.sum())
+    # worth it only when the set is most of the level (a mesh-like graph leaves more than half of its unknowns outside any independent
+    # set) and the remainder is small enough for the dense inverse
+    if not (0 < nC <= max(coarse_size, DENSE_LIMIT // 2) and nF > 0 and nC <= 0.3 * (nC + nF)):
+        return None
+    dinv_e, Pm = elimination_level(A, diag, F, C, lam)
+    dinv_e = np.where(iso, dinv / cheby_first_coefficient(lam), dinv_e)      # decoupled unknowns: solved by the smoother as well
+    R = Pm.T.tocsr()
+    R.sort_indices()
+    AP = (A @ Pm).tocsr()
+    Ac = (R @ AP).tocsr()
+    Ac.sort_indices()
+    S_ = post_smoothed_prolongator(A, dinv_e, lam, Pm, AP)
+    Rt_, U_ = coarse_fused_operators(A, dinv_e, lam, R, S_) if n_levels_so_far else (None, None)
+    return Level(A, dinv_e, lam, Pm, R, S_, Rt_, U_), Ac
+
+
 def build_hierarchy(P: sp.csr_matrix, theta: float = 0.08, max_levels: int = 12, coarse_size: int = 2500,
                     smooth_prolongator: bool = True, agg_distance=2, node_fields=None, split_decoupled: bool = True,
-                    smoother_degree: int = 1) -> Hierarchy:
+                    smoother_degree: int = 1, eliminate_independent: bool = True) -> Hierarchy:
     """Rows with a zero diagonal are inactive: they get no aggregate (zero rows in the prolongator, zero inverse
     diagonal in the smoother), so a field-restricted P yields a hierarchy of that field class only.
 
@@ -223,14 +298,23 @@ def build_hierarchy(P: sp.csr_matrix, theta: float = 0.08, max_levels: int = 12,
     coarsest operator is small enough for the dense inverse -- without this a mesh with tens of thousands of cells ends on a
     level of that many 1x1 blocks plus the extracellular part, smoothed but never solved.
 
+    ``eliminate_independent``: scalar hierarchies only; on a level whose coupled unknowns contain an independent set F (no F-F
+    coupling) such that at most ``coarse_size`` unknowns remain, F is eliminated exactly (``elimination_level``) instead of being
+    aggregated: the coupled potential block of a tissue mesh arrives there as "one unknown per biological cell + the extracellular
+    aggregates", which plain aggregation cannot coarsen (16 505 -> 13 881 -> 11 017 unknowns on the 97^3 surrogate) and which is
+    far too large for a dense inverse, while its Schur complement on the 2 681 extracellular aggregates is small.  Same
+    split-off rule as for decoupled unknowns, with a coupling: the smoother is exact on F (degree-1 smoother only).
+
     ``smoother_degree`` = the Chebyshev degree the cycle will run with: the split relies on every smoothing step being the damped
     Jacobi step ``x += c Dinv (b - A x)`` (degree 1: any number of pre/post sweeps then leaves ``b/d`` in place).  The momentum term of
     a degree >= 2 polynomial overshoots a zero residual, so for those the split is switched off (the unknowns are carried as
     singletons, as before the split existed)."""
     split_decoupled = bool(split_decoupled) and int(smoother_degree) == 1
+    eliminate_independent = bool(eliminate_independent) and int(smoother_degree) == 1
     A = sp.csr_matrix(P, dtype=np.float64)
     A.sort_indices()
     levels = []
+    after_elimination = False
     sync = node_fields is not None and len(node_fields[1]) > 1
     stride, fields = (int(node_fields[0]), tuple(int(f) for f in node_fields[1])) if sync else (1, (0,))
     while True:
@@ -247,11 +331,20 @@ def build_hierarchy(P: sp.csr_matrix, theta: float = 0.08, max_levels: int = 12,
                 iso[f::stride] = iso_n
         n_core = int((active & ~iso).sum())
         n_all = int(active.sum())
-        if n_all <= coarse_size or n_core == 0 or len(levels) >= max_levels - 1:
-            levels.append(Level(A, dinv, lam))
+        if n_all <= coarse_size or n_core == 0 or len(levels) >= max_levels - 1 or after_elimination:
+            levels.append(Level(A, dinv, lam))      # (the remainder of an elimination level is sized for the dense inverse: last level)
             break
         # only decoupled unknowns keep this level too large for the dense inverse: the coupled ones move to a level of their own
         inject = n_core <= coarse_size and n_all > DENSE_LIMIT
+        # a large INDEPENDENT set whose elimination leaves at most a dense-solvable remainder (collapsed cells coupled to the
+        # extracellular aggregates through the membrane: the coupled potential block of a tissue mesh): eliminate it exactly
+        if not inject and not sync and eliminate_independent and n_core <= ELIMINATION_LEVEL_MAX:
+            el = try_elimination_level(A, diag, dinv, active, iso, lam, coarse_size, len(levels))
+            if el is not None:
+                levels.append(el[0])
+                A = el[1]
+                after_elimination = True
+                continue
         if iso.any():
             dinv = np.where(iso, dinv / cheby_first_coefficient(lam), dinv)
             active = active & ~iso
@@ -274,7 +367,7 @@ def build_hierarchy(P: sp.csr_matrix, theta: float = 0.08, max_levels: int = 12,
                     Sf = strength_graph(A[f::stride][:, f::stride].tocsr(), theta)
                     if np.any((np.diff(Sf.indptr) == 0) & (deg0 > 0)) or np.any((diag[f::stride] <= 0.0) & (diag[fields[0]::stride] > 0.0)):
                         return build_hierarchy(P, theta, max_levels, coarse_size, smooth_prolongator, agg_distance, None, split_decoupled,
-                                               smoother_degree)   # unsynchronised
+                                               smoother_degree, eliminate_independent)   # unsynchronised
             act_n = active[fields[0]::stride]
             ian = np.nonzero(act_n)[0]
             if inject:
@@ -408,11 +501,12 @@ def upload(lib, ctx, check, hier: Hierarchy, pre: int = 1, post: int = 1, cheby_
         check(lib.knp_amg_set_coarse(ctx, index, ci_.shape[0], fp(ci_)))
 
 
-def fp32_stored(h: Hierarchy, coarse: bool = False) -> Hierarchy:
+def fp32_stored(h: Hierarchy, coarse: bool = False, level0_uploaded: bool = False) -> Hierarchy:
     """The hierarchy as the library holds it with ``amg_fp32`` (default): level and transfer operator VALUES rounded to
     fp32 (diagonals, vectors and arithmetic stay fp64).  ``coarse``: also the dense coarse inverse -- what the library does for
     the ion-field hierarchy of the block-triangular preconditioner when its cycle runs fused (the potential hierarchy's and
-    the all-field hierarchy's coarse inverses stay fp64).  For checkers that restate the V-cycle."""
+    the all-field hierarchy's coarse inverses stay fp64).  ``level0_uploaded``: the hierarchy's level 0 runs on the uploaded operator
+    (coupled potential block of ``btcc``).  For checkers that restate the V-cycle."""
     import copy
 
     def rnd(M):
@@ -434,4 +528,11 @@ def fp32_stored(h: Hierarchy, coarse: bool = False) -> Hierarchy:
     if out.levels:      # level 0 of the fused cycle applies Pt = A Dinv, computed in fp64 from the fp64 P and rounded once
         l0 = h.levels[0]
         out.levels[0].Pt = rnd((l0.A @ sp.diags(l0.dinv)).tocsr())
+        if level0_uploaded:
+            # potential hierarchy on its uploaded (coupled) level-0 operator (knp_amg_use_native_level0 mode 4): the library scales the
+            # fp32-stored operator, c A32 Dinv, and rounds that to fp32; the fused cycle restated by the oracle multiplies by c again
+            c = cheby_first_coefficient(l0.lambda_max)
+            Pt = rnd((c * (rnd(l0.A) @ sp.diags(l0.dinv))).tocsr())
+            Pt.data /= c
+            out.levels[0].Pt = Pt
     return out

@@ -178,15 +178,17 @@ def _aggregate(crow, col, n, seed, distance):
 
 
 def build_hierarchy(P, theta: float = 0.08, max_levels: int = 12, coarse_size: int = 2500, agg_distance=2, device="cuda", node_fields=None,
-                    split_decoupled: bool = True, smoother_degree: int = 1):
+                    split_decoupled: bool = True, smoother_degree: int = 1, eliminate_independent: bool = True):
     """Device version of ``amg.build_hierarchy`` (same arguments, same kind of result; ``node_fields``: aggregation on the node
     graph of the first field, shared by all fields; ``split_decoupled``: unknowns without off-diagonal entries are solved by the
     smoother and not carried to coarser levels, only with a degree-1 smoother -- see amg.build_hierarchy)."""
     split_decoupled = bool(split_decoupled) and int(smoother_degree) == 1
+    eliminate_independent = bool(eliminate_independent) and int(smoother_degree) == 1
     A = _from_scipy(P, device)
     A_host = sp.csr_matrix(P, dtype=np.float64)
     A_host.sort_indices()
     levels = []
+    after_elimination = False
     sync = node_fields is not None and len(node_fields[1]) > 1
     stride, fields = (int(node_fields[0]), tuple(int(f) for f in node_fields[1])) if sync else (1, (0,))
     while True:
@@ -210,10 +212,20 @@ def build_hierarchy(P, theta: float = 0.08, max_levels: int = 12, coarse_size: i
         any_iso = bool(iso.any())
         n_core = int((active & ~iso).sum())
         n_all = int(active.sum())
-        if n_all <= coarse_size or n_core == 0 or len(levels) >= max_levels - 1:
+        if n_all <= coarse_size or n_core == 0 or len(levels) >= max_levels - 1 or after_elimination:
             levels.append(amg.Level(A_host, dinv.cpu().numpy(), lam))
             break
         inject = n_core <= coarse_size and n_all > amg.DENSE_LIMIT
+        if not inject and not sync and eliminate_independent and n_core <= amg.ELIMINATION_LEVEL_MAX:
+            # small level: the independent-set elimination of amg.build_hierarchy, done by the same host code
+            el = amg.try_elimination_level(A_host, diag.cpu().numpy(), dinv.cpu().numpy(), active.cpu().numpy(), iso.cpu().numpy(), lam,
+                                           coarse_size, len(levels))
+            if el is not None:
+                levels.append(el[0])
+                A_host = el[1]
+                A = _from_scipy(A_host, diag.device)
+                after_elimination = True
+                continue
         if any_iso:
             dinv = torch.where(iso, dinv / amg.cheby_first_coefficient(lam), dinv)
             active = active & ~iso
@@ -233,7 +245,7 @@ def build_hierarchy(P, theta: float = 0.08, max_levels: int = 12, coarse_size: i
                     Af = _from_coo(torch.div(r_[mf], stride, rounding_mode="floor"), torch.div(c_[mf], stride, rounding_mode="floor"), v_[mf], (nn, nn))
                     degf = torch.bincount(torch.div(_strength(Af, th), nn, rounding_mode="floor"), minlength=nn)
                     if bool(((degf == 0) & (deg0 > 0)).any()) or bool(((diag[f::stride] <= 0) & (diag[f0::stride] > 0)).any()):
-                        return build_hierarchy(P, theta, max_levels, coarse_size, agg_distance, device, None, split_decoupled, smoother_degree)
+                        return build_hierarchy(P, theta, max_levels, coarse_size, agg_distance, device, None, split_decoupled, smoother_degree, eliminate_independent)
             act_n = active[f0::stride]
             ian = torch.nonzero(act_n).squeeze(1)
             n_act_n = int(ian.numel())

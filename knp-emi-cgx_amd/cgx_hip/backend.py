@@ -535,6 +535,31 @@ class Backend:
         P.sort_indices()
         return P
 
+    def set_coupled_potential(self, on=True):
+        self.check(self.lib.knp_pc_set_coupled_potential(self.ctx, 1 if on else 0))
+
+    def precond_phi_csr(self, embedded=True):
+        """The potential block of P (coupled across the membrane after ``set_coupled_potential``): node-indexed CSR, or -- ``embedded``
+        -- placed at the potential unknowns 4*node+3 of an n_dof x n_dof matrix, which is what the hierarchy builders take."""
+        import scipy.sparse as sp
+        sz = (C.c_int64 * _lib.KNP_SZ_COUNT)()
+        self.check(self.lib.knp_get_sizes(self.ctx, sz))
+        nnz = sz[_lib.SZ_NNZ_P_PHI]
+        no = self.n_nodes_owned
+        rp = np.empty(no + 1, dtype=np.int32)
+        ci = np.empty(nnz, dtype=np.int32)
+        va = np.empty(nnz, dtype=np.float64)
+        self.check(self.lib.knp_get_precond_phi_csr(self.ctx, _i32(rp), _i32(ci), _f64(va)))
+        if not embedded:
+            M = sp.csr_matrix((va, ci, rp), shape=(no, self.n_nodes))
+            M.sort_indices()
+            return M
+        rows = np.repeat(4 * np.arange(no, dtype=np.int64) + 3, np.diff(rp))
+        M = sp.csr_matrix((va, (rows, 4 * ci.astype(np.int64) + 3)), shape=(self.n_dof_owned, self.n_dof_local))
+        M.eliminate_zeros()        # right-angled simplices: half of the same-side pairs of a structured mesh have no stiffness coupling
+        M.sort_indices()
+        return M
+
     # ---- step timers (events in the library: one ctypes call per mark, one synchronisation per read) ------------------------
     def timer_mark(self, join_assembly=False):
         self.check(self.lib.knp_timer_mark(self.ctx, 1 if join_assembly else 0))

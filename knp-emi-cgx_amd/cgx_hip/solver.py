@@ -86,6 +86,7 @@ class SolverKNPEMI:
     amg_node_sync = True   # ion hierarchy: aggregate NODES once, all three ion fields share aggregates and sparsity patterns
     amg_split_decoupled = True   # unknowns without off-diagonal entries on a level are solved by its smoother, not coarsened further
     _b_is_final = False
+    btcc_coupled_phi = True  # btcc on one GPU: potential hierarchy on the potential block of A (both sides + membrane coupling), not on P's
     amg_setup = "gpu"      # where the hierarchy is built: "gpu" (torch sparse products, cgx_hip/amg_gpu.py) | "host" (SciPy)
 
     def __init__(self, problem: ProblemKNPEMI, solver_config: dict):
@@ -115,7 +116,8 @@ class SolverKNPEMI:
             if "ksp_max_it" in ks: self.ksp_max_it = int(ks["ksp_max_it"])
             if "gmres_restart" in ks: self.gmres_restart = int(ks["gmres_restart"])
             if "strict" in ks: self.strict = bool(ks["strict"])
-            for k in ("amg_theta", "amg_cheby_degree", "amg_pre", "amg_post", "amg_coarse_size", "amg_replicate_below", "amg_fp32", "amg_setup", "amg_node_sync", "amg_split_decoupled"):
+            for k in ("amg_theta", "amg_cheby_degree", "amg_pre", "amg_post", "amg_coarse_size", "amg_replicate_below", "amg_fp32", "amg_setup", "amg_node_sync", "amg_split_decoupled",
+                      "btcc_coupled_phi"):
                 if k in ks: setattr(self, k, type(getattr(self, k))(ks[k]))
         if self.ksp_type != "gmres":
             raise NotImplementedError(f"ksp_type '{self.ksp_type}': only 'gmres' is implemented natively.")
@@ -163,6 +165,12 @@ class SolverKNPEMI:
     def assemble_preconditioner(self):
         self.print("Assembling preconditioner ...")
         be = self.backend
+        # btcc (native extension) on one GPU: the potential hierarchy is built on the potential block of A as assembled now -- both
+        # sides and their membrane coupling -- instead of P's uncoupled block with the reference's minus sign (24 -> 17
+        # iterations per step on the membrane-dominated lattices, never more on the cubes)
+        self._coupled_phi = bool(self.btcc_coupled_phi and self._pc_kind == _lib.PC_AMG_BT and self.comm.size == 1 and not self.problem.MMS_test
+                                 and not self.problem.dirichlet_bcs and not self.problem.pin_ecs_potential and getattr(self.problem, "P_block_jacobi", True))
+        be.set_coupled_potential(self._coupled_phi)
         be.assemble_precond()
         if self._pc_kind in (_lib.PC_AMG, _lib.PC_AMG_BT) and not getattr(self.problem, "P_block_jacobi", True):
             # the reference's non-block-Jacobi form of P: same diagonal blocks + the (phi,k) coupling, applied as a block forward
@@ -200,11 +208,11 @@ class SolverKNPEMI:
                 self.hierarchies = [self.hierarchy]
             else:
                 hk = build(amg.restrict_to_fields(P, (0, 1, 2)), self.ion_node_fields())
-                hp = build(amg.restrict_to_fields(P, (3,)))
+                hp = build(be.precond_phi_csr()[:, :be.n_dof_owned].tocsr() if self._coupled_phi else amg.restrict_to_fields(P, (3,)))
                 amg.upload(be.lib, be.ctx, be.check, hk, self.amg_pre, self.amg_post, self.amg_cheby_degree, index=0)
                 amg.upload(be.lib, be.ctx, be.check, hp, self.amg_pre, self.amg_post, self.amg_cheby_degree, index=1)
                 be.check(be.lib.knp_amg_use_native_level0(be.ctx, 0, 2))   # ion fields of P
-                be.check(be.lib.knp_amg_use_native_level0(be.ctx, 1, 3))   # potential field of P
+                be.check(be.lib.knp_amg_use_native_level0(be.ctx, 1, 4 if self._coupled_phi else 3))   # potential: uploaded coupled block | P's
                 self.hierarchies = [hk, hp]
                 self.hierarchy = hk
             self.amg_setup_time = time.perf_counter() - tic

@@ -177,6 +177,13 @@ struct KnpAmgHier {
     int node_nf = 0;    // > 0: fields per node with identical patterns on every level (knp_amg_set_node_fields)
     int blocked = 0;    // the fused cycle runs on the node-blocked copies (knp_pc_setup decides)
     int cfused = 0;     // ... and its intermediate levels as two plain products each (Rt, U)
+    // potential hierarchy whose level 0 is the UPLOADED operator (it may couple the two sides of the membrane, which the library's
+    // pair-major P cannot): compact CSR of c A Dinv on node-indexed vectors for the down-leg of the fused cycle
+    int l0_upload = 0;
+    int32_t *at0_rp = nullptr, *at0_ci = nullptr;
+    double* at0_v = nullptr;
+    float* at0_vf = nullptr;
+    int at0_lanes = 8;
     double *pt = nullptr, *pt_phi = nullptr;
     float *pt_f = nullptr, *pt_phi_f = nullptr;
 };
@@ -228,6 +235,8 @@ struct knp_ctx {
     double *d_at = nullptr, *d_ac = nullptr, *d_ax = nullptr;
     int32_t *d_gx_i = nullptr, *d_gx_e = nullptr;
     double* d_p_vals = nullptr;
+    double* d_px = nullptr;          // [n_gp] coupled-potential form of P: the phi_i-phi_e cross entry of every membrane vertex pair
+    int pc_coupled_phi = 0;
     bool have_A = false, have_P = false, have_cc = false;
     // work arrays
     double* d_cbar = nullptr;   // [3*n_c]

@@ -63,6 +63,7 @@ struct FieldPtrs {
 
 static void side_discard(knp_ctx* ctx);
 static DevParams make_params(const knp_ctx* ctx);
+static int64_t phi_block_nnz(const knp_ctx* ctx);
 static int join_asm(knp_ctx* ctx);
 static void free_hier(KnpAmgHier& H);
 static inline int nblocks(int64_t n, int per = NT) { return (int)std::max<int64_t>(1, (n + per - 1) / per); }
@@ -477,7 +478,8 @@ k_gamma_pairs(int64_t n_gp, int n_g, int dim, DevParams P, const int32_t* __rest
               const int32_t* __restrict__ gq_e, const int32_t* __restrict__ gcptr,
               const int32_t* __restrict__ gc_facet, const int32_t* __restrict__ gc_lab,
               const double* __restrict__ fmeas, const double* __restrict__ fmat,
-              const int32_t* __restrict__ pair_ptr, double* __restrict__ at /* P: p_vals */, double* __restrict__ ax) {
+              const int32_t* __restrict__ pair_ptr, double* __restrict__ at /* P: p_vals */, double* __restrict__ ax,
+              double* __restrict__ px = nullptr) {
     int64_t s = (int64_t)blockIdx.x * NT + threadIdx.x;
     if (s >= n_gp) return;
     const int A = grow[s];
@@ -512,6 +514,12 @@ k_gamma_pairs(int64_t n_gp, int n_g, int dim, DevParams P, const int32_t* __rest
         *reinterpret_cast<double2*>(ax + 8 * (size_t)s + 2) = make_double2(-m[2], -m0);
         *reinterpret_cast<double2*>(ax + 8 * (size_t)s + 4) = make_double2(-m[3], -m[4]);
         *reinterpret_cast<double2*>(ax + 8 * (size_t)s + 6) = make_double2(-m[5], -m0);
+    } else if (px) {
+        // coupled-potential form (knp_pc_set_coupled_potential): the potential block of P is the potential block of A at the time of the
+        // preconditioner assembly -- + (C_M/F) M_Gamma on both sides and the phi_i-phi_e coupling - (C_M/F) M_Gamma (KNPEMIx_problem.py:637-638)
+        at[4 * pi + 3] += m0;
+        at[4 * pe + 3] += m0;
+        px[s] = -m0;
     } else {
         at[4 * pi + 3] -= m0;   // KNPEMIx_problem.py:737
         at[4 * pe + 3] -= m0;   // KNPEMIx_problem.py:738
@@ -2582,7 +2590,7 @@ int knp_destroy(knp_ctx* ctx) {
     dev_free(ctx->d_gptr); dev_free(ctx->d_gcol); dev_free(ctx->d_grow); dev_free(ctx->d_gq_i); dev_free(ctx->d_gq_e);
     dev_free(ctx->d_gdiag); dev_free(ctx->d_gcptr); dev_free(ctx->d_gc_facet); dev_free(ctx->d_gc_lab);
     dev_free(ctx->d_at); dev_free(ctx->d_ac); dev_free(ctx->d_ax); dev_free(ctx->d_gx_i); dev_free(ctx->d_gx_e);
-    dev_free(ctx->d_p_vals);
+    dev_free(ctx->d_p_vals); dev_free(ctx->d_px);
     dev_free(ctx->d_cbar); dev_free(ctx->d_fmat); dev_free(ctx->d_fvec);
     dev_free(ctx->d_partial); dev_free(ctx->d_red); dev_free(ctx->d_y); dev_free(ctx->d_vbj); dev_free(ctx->d_gm);
     if (ctx->h_red) (void)hipHostFree(ctx->h_red);
@@ -2624,6 +2632,7 @@ int knp_get_sizes(const knp_ctx* ctx, int64_t* s) {
     s[KNP_SZ_N_GAMMA_PAIRS] = ctx->n_gp;
     s[KNP_SZ_NNZ_P] = 4 * ctx->n_pairs;
     s[KNP_SZ_N_PHI_OWNED] = ctx->g.n_nodes_owned;
+    s[KNP_SZ_NNZ_P_PHI] = phi_block_nnz(ctx);
     return KNP_OK;
 }
 int knp_get_layout(const knp_ctx* ctx, int32_t* ni, int32_t* ne) {
@@ -2956,6 +2965,60 @@ int knp_assemble_matrix_async(knp_ctx* ctx, const knp_fields* fields) {
     return KNP_OK;
 }
 
+// Form of the potential block of P.  0 (default): the reference's block-Jacobi form, - (C_M/F) M_Gamma on each side, sides uncoupled
+// (KNPEMIx_problem.py:735-738).  1: the potential block of A itself at assembly time, + (C_M/F) M_Gamma and the phi_i-phi_e
+// coupling (:637-638) -- what `btcc` builds its potential hierarchy on: in membrane-dominated meshes the coupling is the dominant
+// term of that block, and the uncoupled form costs 40 % more GMRES iterations (preconditioners).  Call before
+// knp_assemble_precond; knp_get_precond_phi_csr exports the coupled block.
+int knp_pc_set_coupled_potential(knp_ctx* ctx, int32_t on) {
+    CHECK_CTX(ctx);
+    side_discard(ctx);
+    ctx->pc_coupled_phi = on ? 1 : 0;
+    if (on && !ctx->d_px) {
+        HIPCHK(hipMalloc((void**)&ctx->d_px, (size_t)std::max<int64_t>(ctx->n_gp, 1) * sizeof(double)));
+        HIPCHK(hipMemset(ctx->d_px, 0, (size_t)std::max<int64_t>(ctx->n_gp, 1) * sizeof(double)));
+    }
+    ctx->have_P = false;
+    return KNP_OK;
+}
+// number of entries / CSR of the potential block of P on NODE-indexed rows and columns (owned rows, local columns): same-side node
+// pairs and, in the coupled form, the other side's node at every membrane neighbour
+static int64_t phi_block_nnz(const knp_ctx* ctx) {
+    const KnpHostGraph& g = ctx->g;
+    int64_t nnz = g.pair_ptr[g.n_nodes_owned];
+    if (ctx->pc_coupled_phi)
+        for (int n = 0; n < g.n_nodes_owned; ++n) {
+            const int A = g.node_gv[n];
+            if (A >= 0) nnz += g.gptr[A + 1] - g.gptr[A];
+        }
+    return nnz;
+}
+int knp_get_precond_phi_csr(const knp_ctx* cctx, int32_t* rp, int32_t* ci, double* vals) {
+    knp_ctx* ctx = const_cast<knp_ctx*>(cctx);
+    if (!ctx || !rp || !ci || !vals) return KNP_E_ARG;
+    if (!ctx->have_P) { ctx->err = "P not assembled"; return KNP_E_STATE; }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    std::vector<double> pm((size_t)4 * ctx->n_pairs), px;
+    HIPCHK(hipMemcpy(pm.data(), ctx->d_p_vals, pm.size() * sizeof(double), hipMemcpyDeviceToHost));
+    if (ctx->pc_coupled_phi && ctx->n_gp > 0) {
+        px.resize((size_t)ctx->n_gp);
+        HIPCHK(hipMemcpy(px.data(), ctx->d_px, px.size() * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    const KnpHostGraph& g = ctx->g;
+    int64_t k = 0;
+    for (int n = 0; n < g.n_nodes_owned; ++n) {
+        rp[n] = (int32_t)k;
+        for (int p = g.pair_ptr[n]; p < g.pair_ptr[n + 1]; ++p) { ci[k] = g.pair_col[p]; vals[k++] = pm[(size_t)4 * p + 3]; }
+        const int A = g.node_gv[n];
+        if (ctx->pc_coupled_phi && A >= 0) {
+            const std::vector<int32_t>& gx = g.node_side[n] ? g.gx_e : g.gx_i;
+            for (int s = g.gptr[A]; s < g.gptr[A + 1]; ++s) { ci[k] = gx[s]; vals[k++] = px[s]; }
+        }
+    }
+    rp[g.n_nodes_owned] = (int32_t)k;
+    return KNP_OK;
+}
+
 int knp_assemble_precond(knp_ctx* ctx, const knp_fields* fields) {
     CHECK_CTX(ctx);
     side_discard(ctx);
@@ -2972,7 +3035,7 @@ int knp_assemble_precond(knp_ctx* ctx, const knp_fields* fields) {
         hipLaunchKernelGGL((k_gamma_pairs<true>), dim3(nblocks(ctx->n_gp)), dim3(NT), 0, ctx->stream, ctx->n_gp, g.n_g, g.dim, P,
                            ctx->d_grow, ctx->d_gptr, ctx->d_gv_node_i, ctx->d_gv_node_e, ctx->d_gq_i, ctx->d_gq_e,
                            ctx->d_gcptr, ctx->d_gc_facet, ctx->d_gc_lab, ctx->d_fmeas, ctx->d_fmat, ctx->d_pair_ptr,
-                           ctx->d_p_vals, nullptr);
+                           ctx->d_p_vals, nullptr, ctx->pc_coupled_phi ? ctx->d_px : nullptr);
     if (ctx->n_bc > 0)
         hipLaunchKernelGGL(k_dirichlet_rows_P, dim3(nblocks(ctx->n_bc)), dim3(NT), 0, ctx->stream, ctx->n_bc, ctx->d_bc_dofs, ctx->d_pair_ptr,
                            ctx->d_pair_col, ctx->d_p_vals);
@@ -3342,6 +3405,7 @@ static void free_hier(KnpAmgHier& H) {
     }
     dev_free(H.cinv); dev_free(H.cinv_f);
     dev_free(H.pt); dev_free(H.pt_phi); dev_free(H.pt_f); dev_free(H.pt_phi_f);
+    dev_free(H.at0_rp); dev_free(H.at0_ci); dev_free(H.at0_v); dev_free(H.at0_vf); H.l0_upload = 0;
     H.nc = 0; H.levels = 0; H.native0 = 0; H.fused = 0; H.node_nf = 0; H.blocked = 0; H.cfused = 0;
 }
 int knp_amg_reset(knp_ctx* ctx, int32_t hier, int32_t n_levels, int32_t pre, int32_t post, int32_t cheby) {
@@ -3549,11 +3613,35 @@ int knp_amg_set_precision(knp_ctx* ctx, int32_t fp32_storage) {
 }
 // level-0 data of the fused cycle: Pt = P Dinv with the hierarchy's own inverse diagonal (zero on the fields it does not act on);
 // potential-only hierarchies additionally get node-indexed copies of the index arrays that refer to level-0 rows
+__global__ void __launch_bounds__(NT) k_gather_rowptr4(int n, const int32_t* __restrict__ rp, int off, int32_t* __restrict__ out) {
+    for (int i = blockIdx.x * NT + threadIdx.x; i <= n; i += gridDim.x * NT) out[i] = rp[i < n ? 4 * (size_t)i + off : 4 * (size_t)n];
+}
 static int build_fused_data(knp_ctx* ctx, KnpAmgHier& H) {
     dev_free(H.pt); dev_free(H.pt_phi); dev_free(H.pt_f); dev_free(H.pt_phi_f);
+    dev_free(H.at0_rp); dev_free(H.at0_ci); dev_free(H.at0_v); dev_free(H.at0_vf);
     KnpAmgLevel& L = H.lv[0];
     dev_free(L.R_ci_c); dev_free(L.S_act_rows_c); dev_free(L.dinv_c);
     if (!H.native0 || H.levels < 2 || !L.inv_diag || !L.S_rp) return KNP_OK;
+    if (H.l0_upload) {
+        // potential hierarchy on its uploaded level-0 operator (rows 4 node + 3 of an n_dof x n_dof CSR, every other row empty): the
+        // compact CSR of c A Dinv on node-indexed vectors -- row pointer of the potential rows, columns / 4, values scaled
+        if (H.native0 != 3 || ctx->g.n_nodes != ctx->g.n_nodes_owned || !L.A_rp || L.A_nnz <= 0) { ctx->err = "level 0 from the uploaded operator: potential hierarchy on one GPU only"; return KNP_E_STATE; }
+        const int nn = ctx->g.n_nodes_owned;
+        const double c = 1.0 / (0.5 * (1.1 + 0.1) * L.lambda_max);
+        const int nblk = (int)std::min<int64_t>(nblocks(L.A_nnz), 8192);
+        HIPCHK(hipMalloc((void**)&H.at0_rp, ((size_t)nn + 1) * sizeof(int32_t)));
+        HIPCHK(hipMalloc((void**)&H.at0_ci, (size_t)L.A_nnz * sizeof(int32_t)));
+        hipLaunchKernelGGL(k_gather_rowptr4, dim3(std::min(nblocks(nn + 1), 4096)), dim3(NT), 0, ctx->stream, nn, L.A_rp, 3, H.at0_rp);
+        hipLaunchKernelGGL(k_shift2, dim3(nblk), dim3(NT), 0, ctx->stream, L.A_nnz, L.A_ci, H.at0_ci);
+        if (L.A_vf) {
+            HIPCHK(hipMalloc((void**)&H.at0_vf, (size_t)L.A_nnz * sizeof(float)));
+            hipLaunchKernelGGL((k_build_at<float, float>), dim3(nblk), dim3(NT), 0, ctx->stream, L.A_nnz, L.A_ci, L.A_vf, L.inv_diag, c, H.at0_vf);
+        } else {
+            HIPCHK(hipMalloc((void**)&H.at0_v, (size_t)L.A_nnz * sizeof(double)));
+            hipLaunchKernelGGL((k_build_at<double, double>), dim3(nblk), dim3(NT), 0, ctx->stream, L.A_nnz, L.A_ci, L.A_v, L.inv_diag, c, H.at0_v);
+        }
+        H.at0_lanes = pick_lanes((double)L.A_nnz / std::max(nn, 1), 0);
+    }
     const int64_t np = ctx->n_pairs;
     const int nblk = (int)std::min<int64_t>(nblocks(np), 8192);
     const bool phi = H.native0 == 3;
@@ -3567,7 +3655,9 @@ static int build_fused_data(knp_ctx* ctx, KnpAmgHier& H) {
         KCHK(halo_update(ctx, dinv_tmp));
         dinv_loc = dinv_tmp;
     }
-    if (ctx->amg_fp32) {
+    if (H.l0_upload) {
+        // (no pair-major P Dinv: the down-leg runs on at0)
+    } else if (ctx->amg_fp32) {
         if (phi) HIPCHK(hipMalloc((void**)&H.pt_phi_f, std::max<int64_t>(np, 1) * sizeof(float)));
         else HIPCHK(hipMalloc((void**)&H.pt_f, std::max<int64_t>(4 * np, 1) * sizeof(float)));
         hipLaunchKernelGGL((k_build_pt<float>), dim3(nblk), dim3(NT), 0, ctx->stream, np, ctx->d_pair_col, ctx->d_p_vals, dinv_loc, H.pt_f, H.pt_phi_f);
@@ -3607,8 +3697,10 @@ static int build_fused_data(knp_ctx* ctx, KnpAmgHier& H) {
 
 int knp_amg_use_native_level0(knp_ctx* ctx, int32_t hier, int32_t mode) {
     CHECK_CTX(ctx);
-    if (hier < 0 || hier >= KNP_MAX_HIER || mode < 0 || mode > 3) { ctx->err = "bad arguments"; return KNP_E_ARG; }
+    if (hier < 0 || hier >= KNP_MAX_HIER || mode < 0 || mode > 4) { ctx->err = "bad arguments"; return KNP_E_ARG; }
     if (mode && !ctx->have_P) { ctx->err = "P not assembled"; return KNP_E_STATE; }
+    ctx->hier[hier].l0_upload = mode == 4 ? 1 : 0;     // mode 4: potential only, level 0 = the uploaded operator (may couple the sides)
+    if (mode == 4) mode = 3;
     ctx->hier[hier].native0 = mode;
     KCHK(build_fused_data(ctx, ctx->hier[hier]));
     if (mode && ctx->amg_fp32) {   // fp32 shadow of the pair-major P for the level-0 node kernels
@@ -3819,7 +3911,7 @@ static double* amg_vcycle(knp_ctx* ctx, KnpAmgHier& H, int l, const double* b, d
 static bool fused_eligible(const knp_ctx* ctx, const KnpAmgHier& H) {
     const bool off = getenv("KNP_FUSED") && atoi(getenv("KNP_FUSED")) == 0;   // read at every knp_pc_setup
     if (off || !H.native0 || H.levels < 2 || H.cheby != 1 || H.pre != 1 || H.post != 1 || H.nc <= 0) return false;
-    if (!(H.pt || H.pt_f || H.pt_phi || H.pt_phi_f)) return false;
+    if (!(H.pt || H.pt_f || H.pt_phi || H.pt_phi_f || H.at0_rp)) return false;
     if (ctx->level_comm || ctx->p2p || ctx->halo) return false;
     for (int l = 0; l < H.levels - 1; ++l) {
         const KnpAmgLevel& L = H.lv[l];
@@ -3840,7 +3932,10 @@ static void amg_cycle_fused(knp_ctx* ctx, KnpAmgHier& H, const double* b, double
     // level 0, down: r0 = b - c Pt b
     const double c0 = cheb_c(L0);
     const int nn = ctx->g.n_nodes_owned;
-    if (phi) {
+    if (phi && H.at0_rp) {   // level 0 = the uploaded (coupled) potential block: r = b - (c A Dinv) b on node-indexed vectors
+        if (H.at0_vf) launch_spmv_t<1, 0, float>(st, H.at0_lanes, nn, H.at0_rp, H.at0_ci, H.at0_vf, b, b, L0.r);
+        else launch_spmv_t<1, 0, double>(st, H.at0_lanes, nn, H.at0_rp, H.at0_ci, H.at0_v, b, b, L0.r);
+    } else if (phi) {
         const int Gp = std::max(2, ctx->pc_group / 2);   // four trips per lane in flight: a quarter of the pairs per lane
         if (H.pt_phi_f) launch_l0_down<float>(st, 2, Gp, nn, ctx->d_pair_ptr, ctx->d_pair_col, H.pt_phi_f, b, c0, L0.r);
         else launch_l0_down<double>(st, 2, Gp, nn, ctx->d_pair_ptr, ctx->d_pair_col, H.pt_phi, b, c0, L0.r);
@@ -3996,6 +4091,9 @@ int knp_pc_setup(knp_ctx* ctx, int32_t kind) {
         const bool ok = fused_eligible(ctx, ctx->hier[0]) && fused_eligible(ctx, ctx->hier[1]) && ctx->hier[1].native0 == 3 && ctx->hier[0].native0 == 2 &&
                         ctx->hier[1].lv[0].S_n_act > 0 && ctx->hier[1].lv[0].S_act_rows_c && ctx->hier[1].lv[0].R_ci_c;
         ctx->hier[0].fused = ctx->hier[1].fused = ok ? 1 : 0;
+        // a potential hierarchy on its uploaded (coupled) level-0 operator outside the fused cycle: the level-by-level cycle must
+        // not smooth with the library's own uncoupled P on level 0 -- it takes the uploaded CSR like any other level
+        if (!ok && ctx->hier[1].l0_upload) ctx->hier[1].native0 = 0;
     }
     for (int h = 0; h < KNP_MAX_HIER; ++h) {   // node-blocked operators under the fused cycle: every level must have them
         KnpAmgHier& H = ctx->hier[h];

@@ -672,6 +672,18 @@ class OracleKNPEMI:
     def potential_norms(self):
         return self.l2_norm(self.phi[0], 0), self.l2_norm(self.phi[1], 1)
 
+    def potential_block_of_A(self):
+        """The potential block of A at the current state -- both sides and their membrane coupling (KNPEMIx_problem.py:633-638) --
+        placed at the potential unknowns of an n_dof x n_dof matrix: what the native ``btcc`` preconditioner builds its potential
+        hierarchy on (knp_pc_set_coupled_potential) instead of P's uncoupled block."""
+        n = self.n_dof
+        pidx = np.arange(3, n, 4)
+        coo = self.assemble_A().tocsr()[pidx][:, pidx].tocoo()
+        M = sp.csr_matrix((coo.data, (pidx[coo.row], pidx[coo.col])), shape=(n, n))
+        M.eliminate_zeros()
+        M.sort_indices()
+        return M
+
     def node_coords(self):
         """coordinates of the nodes (vertex, side) in node order: input of the nested-dissection ordering"""
         L = self.lay

@@ -1,0 +1,125 @@
+"""Developer experiment (CPU, oracle only): GMRES iterations per step on a membrane-dominated tissue lattice for variants of the
+block-triangular preconditioner.   python tests/devtools/tissue_pc_experiment.py [N m] [steps]"""
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for p in ("knp-emi-cgx_amd", "oracle", "tests"):
+    sys.path.insert(0, os.path.join(ROOT, p))
+import numpy as np, scipy.sparse as sp, scipy.sparse.linalg as spla
+import knpemi_oracle as K
+from cgx_hip import amg, mesh as M
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 25
+m = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+which = sys.argv[4].split(",") if len(sys.argv) > 4 else None
+ION = tuple(int(v) for v in sys.argv[5].split(",")) if len(sys.argv) > 5 else (1, 1, 1)
+PHI = tuple(int(v) for v in sys.argv[6].split(",")) if len(sys.argv) > 6 else (1, 1, 1)
+DIST = tuple(int(v) for v in sys.argv[7].split(",")) if len(sys.argv) > 7 else (2,)
+print("ion cycle (pre, post, degree):", ION, " potential cycle:", PHI, " ion aggregation distance per level:", DIST)
+name = f"tissue3d_{N}_{m}_w1.xdmf"
+coords, cells, tags, ft, _ = M.load_mesh(name, name, 1e-6)
+intra = tuple(int(t) for t in np.unique(tags) if t != 1)
+gam, gt, _ = M.gamma_integration_entities(cells, tags, intra, (1,), "intra")
+
+
+def make():
+    return K.OracleKNPEMI(coords / 1e-6, cells, tags, intra_tags=intra, extra_tag=1, gamma=gam, gamma_tag=gt,
+                          models=[K.Model("neuronal_ct", intra), K.Model("hh", intra), K.Model("atp", intra)], mesh_conversion_factor=1e-6,
+                          stimulus_tags=intra, stimulus_region=(0, 0.0, 0.5e-6))
+
+
+o0 = make()
+n = o0.n_dof
+pidx = np.arange(3, n, 4)
+kidx = np.setdiff1d(np.arange(n), pidx)
+print(f"{name}: {len(intra)} cells, n_dof {n}, membrane vertex fraction {(np.sum((o0.lay.node_i >= 0) & (o0.lay.node_e >= 0)) / o0.n_v):.2f}")
+
+
+def exact_block(Mat, idx):
+    """pseudo-solve on a sub-block (singular blocks: tiny shift)"""
+    B = Mat[idx][:, idx].tocsc()
+    sh = 1e-10 * abs(B.diagonal()).max()
+    lu = spla.splu(B + sh * sp.identity(B.shape[0], format="csc"))
+    def ap(r):
+        z = np.zeros(Mat.shape[0]); z[idx] = lu.solve(r[idx]); return z
+    return ap
+
+
+def variant(o, kind):
+    P = o.assemble_P()
+    hk = amg.build_hierarchy(amg.restrict_to_fields(P, (0, 1, 2)), theta=0.08, coarse_size=2500, node_fields=(4, (0, 1, 2)), smoother_degree=ION[2], agg_distance=list(DIST))
+    hp = amg.build_hierarchy(amg.restrict_to_fields(P, (3,)), theta=0.08, coarse_size=2500)
+    ipre, ipost, ideg = ION
+    Vk = K.pc_amg_vcycle(hk.levels, hk.coarse_inv, ipre, ipost, ideg)
+    Vp = K.pc_amg_vcycle(hp.levels, hp.coarse_inv, PHI[0], PHI[1], PHI[2])
+    nn = o.lay.n_nodes
+    Mn = sp.coo_matrix((o.Mloc.ravel(), (o.rowsA.ravel(), o.colsA.ravel())), shape=(nn, nn)).tocsr()
+    ML = np.asarray(Mn.sum(axis=1)).ravel()
+    zz = np.array(o.p.z)
+    state = {}
+
+    def setup_A():
+        A = o.current_A.tocsr()
+        if "Aphi" in state and state["A_id"] is A:
+            return
+        state["A_id"] = A
+        if kind in ("B", "D", "F"):
+            state["Aphi"] = exact_block(A, pidx)
+        if kind in ("E", "G"):
+            App = sp.csr_matrix((n, n))
+            Asub = A[pidx][:, pidx].tocsr()
+            # coupled potential block embedded at the potential unknowns
+            coo = Asub.tocoo()
+            App = sp.csr_matrix((coo.data, (pidx[coo.row], pidx[coo.col])), shape=(n, n))
+            h = amg.build_hierarchy(App, theta=0.08, coarse_size=2500)
+            state["Vc"] = K.pc_amg_vcycle(h.levels, h.coarse_inv, PHI[0], PHI[1], PHI[2])
+            state["rows"] = h.describe()["rows"]
+        if kind in ("C", "D"):
+            state["Pk"] = exact_block(P, kidx)
+
+    def apply(r):
+        setup_A()
+        p = o.p
+        s = np.zeros(nn)
+        for side, nodes in ((0, o.lay.node_i), (1, o.lay.node_e)):
+            v = np.nonzero(nodes >= 0)[0]
+            s[nodes[v]] = sum(p.z[j] ** 2 * o.k[side][j][v] for j in range(3))
+        cc = p.psi / (s * ML)
+        z = state["Pk"](r) if kind in ("C", "D") else Vk(r)
+        z[pidx] = 0.0
+        zr = sum(zz[j] * r[j::4] for j in range(3))
+        zk = sum(zz[j] * z[j::4] for j in range(3))
+        t = np.zeros_like(r)
+        t[pidx] = r[pidx] - zr + Mn @ zk
+        if kind in ("B", "D"):
+            w = state["Aphi"](t)
+        elif kind == "F":           # exact coupled potential solve, no Schur term
+            w = state["Aphi"](t)
+            z[pidx] = w[pidx]
+            return z
+        elif kind == "E":
+            w = state["Vc"](t)
+        elif kind == "G":           # V-cycle on the coupled block, no Schur term
+            w = state["Vc"](t)
+            z[pidx] = w[pidx]
+            return z
+        else:
+            w = Vp(t)
+        z[pidx] = w[pidx] + cc * t[pidx]
+        return z
+    return apply, state
+
+
+names = {"A": "btcc as built (V_k, V_phi on P_phiphi, cc)", "B": "V_k + EXACT coupled A_phiphi + cc", "C": "EXACT ions + V_phi(P) + cc",
+         "D": "EXACT ions + EXACT coupled A_phiphi + cc", "E": "V_k + V-cycle on COUPLED A_phiphi + cc", "F": "V_k + EXACT coupled A_phiphi, no cc",
+         "G": "V_k + V-cycle on COUPLED A_phiphi, no cc"}
+for kind in (which or ["A", "B", "C", "D", "E", "F", "G"]):
+    o = make()
+    t0 = time.perf_counter()
+    st = {}
+    def fac(P, kind=kind, o=o):
+        ap, s_ = variant(o, kind)
+        st.update(s=s_)
+        return ap
+    _, its = o.run(steps, solver="gmres", pc=fac, rtol=1e-9)
+    print(f"{kind}: {names[kind]:55s} its/step {its}  ({time.perf_counter() - t0:.0f} s) {st['s'].get('rows', '')}", flush=True)

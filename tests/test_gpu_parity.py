@@ -201,7 +201,7 @@ def test_btcc_iterates_match_oracle(N, kind, steps, fp32):
     s = run_native(cfg)
     hk, hp = s.hierarchies
     if fp32:
-        hk, hp = fp32_stored(hk, coarse=bool(s.backend.stats()["fused"])), fp32_stored(hp)
+        hk, hp = fp32_stored(hk, coarse=bool(s.backend.stats()["fused"])), fp32_stored(hp, level0_uploaded=s._coupled_phi)
     assert len(hk.levels) >= 2 and len(hp.levels) >= 2
     o = make_oracle(N, kind)
     xo, its = o.run(steps, solver="gmres", rtol=1e-9,
@@ -514,7 +514,7 @@ def test_non_block_jacobi_form_of_P(N, kind, monkeypatch):
     assert s._pc_kind == _lib.PC_AMG_LT and not s.problem.P_block_jacobi
     hk, hp = s.hierarchies
     fused = bool(s.backend.stats()["fused"])
-    hk, hp = fp32_stored(hk, coarse=fused), fp32_stored(hp)
+    hk, hp = fp32_stored(hk, coarse=fused), fp32_stored(hp, level0_uploaded=getattr(s, "_coupled_phi", False))
     o = make_oracle(N, kind)
     xo, its = o.run(2, solver="gmres", rtol=1e-10, pc=lambda P: K.pc_block_lower(o, hk, hp, s.amg_pre, s.amg_post, s.amg_cheby_degree, fused=fused))
     assert its == list(s.iterations)

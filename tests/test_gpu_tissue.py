@@ -160,7 +160,8 @@ def test_membrane_dominated_surrogate_at_scale():
     def fac(P):
         hk = amg.fp32_stored(amg.build_hierarchy(amg.restrict_to_fields(P, (0, 1, 2)), theta=s.amg_theta, coarse_size=s.amg_coarse_size,
                                                  node_fields=s.ion_node_fields()), coarse=True)
-        hp = amg.fp32_stored(amg.build_hierarchy(amg.restrict_to_fields(P, (3,)), theta=s.amg_theta, coarse_size=s.amg_coarse_size))
+        hp = amg.fp32_stored(amg.build_hierarchy(o.potential_block_of_A() if s._coupled_phi else amg.restrict_to_fields(P, (3,)), theta=s.amg_theta,
+                                                 coarse_size=s.amg_coarse_size), level0_uploaded=s._coupled_phi)
         return K.pc_btcc(o, hk, hp, s.amg_pre, s.amg_post, s.amg_cheby_degree, fused=True)
     _, its = o.run(2, solver="gmres", pc=fac, rtol=1e-9)
     assert its == list(s.iterations[:2]), (its, s.iterations)
@@ -201,7 +202,8 @@ def test_many_cells_split_off_the_hierarchy(monkeypatch):
     def fac(P):
         hko = amg.fp32_stored(amg.build_hierarchy(amg.restrict_to_fields(P, (0, 1, 2)), theta=s.amg_theta, coarse_size=s.amg_coarse_size,
                                                   node_fields=s.ion_node_fields()), coarse=True)
-        hpo = amg.fp32_stored(amg.build_hierarchy(amg.restrict_to_fields(P, (3,)), theta=s.amg_theta, coarse_size=s.amg_coarse_size))
+        hpo = amg.fp32_stored(amg.build_hierarchy(o.potential_block_of_A() if s._coupled_phi else amg.restrict_to_fields(P, (3,)), theta=s.amg_theta,
+                                                  coarse_size=s.amg_coarse_size), level0_uploaded=s._coupled_phi)
         assert hko.describe()["rows"] == hk.describe()["rows"] and hpo.describe()["rows"] == hp.describe()["rows"]
         return K.pc_btcc(o, hko, hpo, s.amg_pre, s.amg_post, s.amg_cheby_degree, fused=True)
     _, its = o.run(2, solver="gmres", pc=fac, rtol=1e-9)
