@@ -338,6 +338,9 @@ enum { KNP_ST_BNORM = 0 /* ||B b|| of the last solve */, KNP_ST_ALLREDUCE = 1 /*
        KNP_ST_BLOCKED = 6 /* bit h set: the fused cycle of hierarchy h runs on node-blocked operators */,
        KNP_ST_FUSED_LEVELS = 7 /* levels >= 1 that run in fused form inside the level-by-level cycle, all hierarchies */, KNP_ST_COUNT = 8 };
 int knp_get_stats(const knp_ctx* ctx, double* out /* host [KNP_ST_COUNT] */);
+/* bytes the kernels of one application must move, from the sizes of the arrays they read and write (per-class roofline): [0] SpMV on A,
+ * [1] one preconditioner application, [2] matrix assembly of one step, [3] right-hand side assembly, [4] one owned vector */
+int knp_get_traffic_model(const knp_ctx* ctx, double* out /* host [5] */);
 
 #ifdef __cplusplus
 }

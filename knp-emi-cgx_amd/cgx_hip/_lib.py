@@ -121,6 +121,7 @@ SIGNATURES = {
     "knp_profile_get": (C.c_int, [vp, C.c_int32, f64p, i64p]),
     "knp_profile_reset": (C.c_int, [vp]),
     "knp_get_stats": (C.c_int, [vp, f64p]),
+    "knp_get_traffic_model": (C.c_int, [vp, f64p]),
 }
 
 _lib = None

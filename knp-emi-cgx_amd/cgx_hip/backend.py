@@ -595,6 +595,12 @@ class Backend:
         return {"bnorm": out[0], "allreduces": int(out[1]), "halos": int(out[2]), "readbacks": int(out[3]), "fused": int(out[4]),
                 "norm_fallbacks": int(out[5]), "blocked": int(out[6]), "fused_levels": int(out[7])}
 
+    def traffic_model(self):
+        """bytes one application of each kernel class must move (knp_get_traffic_model)"""
+        out = (C.c_double * 5)()
+        self.check(self.lib.knp_get_traffic_model(self.ctx, out))
+        return {"spmv": out[0], "pc": out[1], "assembly_matrix": out[2], "assembly_rhs": out[3], "vector": out[4]}
+
     def profile_get(self):
         names = ["spmv", "orthogonalisation", "pc", "assembly", "other"]
         out = {}

@@ -113,6 +113,7 @@ struct KnpBlockedCsr {
     float4* ev = nullptr;    // nf == 3: {v0, v1, v2, bit pattern of the column node}; nf == 4: {v0, v1, v2, v3}
     int32_t* ci = nullptr;   // nf == 4 only
     int lanes = 4;
+    int64_t nnz = 0;         // node entries
 };
 
 struct KnpAmgLevel {
@@ -157,7 +158,7 @@ struct KnpAmgLevel {
     KnpBlockedCsr bA, bR, bS;   // node-blocked copies (hierarchies with node_nf > 0, fp32 storage): level operator, restrictor, S
     // levels >= 1 in fused form inside the level-by-level cycle (distributed hierarchies and their replicated tails):
     // At = c A Dinv on the pattern of A (ghost columns scaled with the ghost inverse diagonal), knp_pc_setup builds it
-    int64_t A_nnz = 0;
+    int64_t A_nnz = 0, R_nnz = 0, S_nnz = 0, Rt_nnz = 0, U_nnz = 0;
     int lfused = 0;
     double* At_v = nullptr;
     float* At_vf = nullptr;

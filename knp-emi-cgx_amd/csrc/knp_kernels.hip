@@ -3371,6 +3371,7 @@ static int build_blocked(knp_ctx* ctx, int nf, int n_rows_scalar, int rs, int cs
     KCHK(dev_upload(ctx, &out->ev, ev));
     if (nf == 4) KCHK(dev_upload(ctx, &out->ci, bci));
     out->n_rows = nn;
+    out->nnz = nnz;
     static const double scale = getenv("KNP_LANE_SCALE_B") ? atof(getenv("KNP_LANE_SCALE_B")) : 1.0;
     // four entries in flight per lane; measured on MI355X (cube 136^3 / 512^2): about 4 entries per lane for S and the level
     // operators, 2 for the restrictors (long rows whose gathers of the fine residual miss the caches more often)
@@ -3489,6 +3490,7 @@ int knp_amg_set_level(knp_ctx* ctx, int32_t hier, int32_t level, int32_t n_rows,
         KCHK(build_prolong_rows(ctx, L, n_rows, P_rp));
         if (L.P_n_act > 0) L.P_lanes = pick_lanes((double)nnzP / L.P_n_act, 1);
         L.R_lanes = pick_lanes((double)nnzR / n_coarse, 2);
+        L.R_nnz = nnzR;
         if (H.node_nf > 0 && ctx->amg_fp32) KCHK(build_blocked(ctx, H.node_nf, n_coarse, H.node_nf, level == 0 ? 4 : H.node_nf, R_rp, R_ci, R_v, &L.bR, true));
     }
     if (H.node_nf > 0 && ctx->amg_fp32 && level > 0) KCHK(build_blocked(ctx, H.node_nf, n_rows, H.node_nf, H.node_nf, A_rp, A_ci, A_v, &L.bA));
@@ -3547,6 +3549,7 @@ int knp_amg_set_level_smoothed(knp_ctx* ctx, int32_t hier, int32_t level, int32_
         KCHK(dev_upload_raw(ctx, &L.S_v, S_v, (size_t)nnzS));
     }
     L.S_rows = n_rows;
+    L.S_nnz = nnzS;
     std::vector<double> dinv_host((size_t)n_rows);
     HIPCHK(hipMemcpy(dinv_host.data(), L.inv_diag, (size_t)n_rows * sizeof(double), hipMemcpyDeviceToHost));
     KCHK(build_act_rows(ctx, n_rows, S_rp, &L.S_act_rows, &L.S_act_rp, &L.S_n_act, dinv_host.data()));
@@ -3586,6 +3589,7 @@ int knp_amg_set_level_coarse_fused(knp_ctx* ctx, int32_t hier, int32_t level, in
         KCHK(dev_upload_raw(ctx, &L.U_v, U_v, (size_t)nnzU));
     }
     L.Rt_lanes = pick_lanes((double)nnzR / std::max(Rt_rows, 1), 2);
+    L.Rt_nnz = nnzR; L.U_nnz = nnzU;
     L.U_lanes = pick_lanes((double)nnzU / std::max(U_rows, 1), 0);
     const int nf = ctx->hier[hier].node_nf;
     if (nf > 0 && ctx->amg_fp32) {
@@ -4797,6 +4801,62 @@ int knp_profile_reset(knp_ctx* ctx) {
     KCHK(prof_collect(ctx));
     for (int i = 0; i < KNP_NPROF; ++i) { ctx->prof_ms[i] = 0; ctx->prof_n[i] = 0; }
     ctx->n_allreduce = ctx->n_halo = ctx->n_readback = ctx->n_norm_fallback = 0;
+    return KNP_OK;
+}
+// Bytes the kernels of one application must move, from the sizes of the arrays they read and write (the "algorithmic bytes" of the
+// per-class roofline): [0] SpMV on A, [1] one preconditioner application (all hierarchies of the current kind, the path
+// knp_pc_setup selected), [2] matrix assembly of one step (entries that depend on the previous solution), [3] right-hand side
+// assembly, [4] bytes of ONE owned vector (the orthogonalisation of iteration j moves (2 (j + 1) + 3) of these).
+static double cycle_bytes(const knp_ctx* ctx, const KnpAmgHier& H) {
+    if (H.levels < 1) return 0.0;
+    const double vs = H.cinv_f || ctx->amg_fp32 ? 4.0 : 8.0;
+    double b = 0.0;
+    const int nl = H.levels;
+    const int nf0 = H.native0 == 1 ? 4 : H.native0 == 2 ? 3 : 1;
+    const double n0 = (double)ctx->g.n_nodes_owned;
+    auto blocked = [&](const KnpBlockedCsr& M, int nf) { return (double)M.nnz * (nf == 4 ? 20.0 : 16.0) + 4.0 * (M.n_rows + 1); };
+    auto scalar = [&](int64_t nnz, int rows) { return (double)nnz * (vs + 4.0) + 4.0 * (rows + 1); };
+    // level 0, down: P Dinv of the library's own P (values per pair and field + neighbour index) or the uploaded compact operator
+    if (H.at0_rp) b += scalar(H.lv[0].A_nnz, ctx->g.n_nodes_owned);
+    else if (H.native0) b += (double)ctx->n_pairs * (vs * nf0 + 4.0) + 4.0 * (n0 + 1);
+    else b += scalar(H.lv[0].A_nnz, H.lv[0].n);
+    b += 8.0 * n0 * nf0 * 3.0;                                     // b gathered, b read, r written
+    for (int l = 0; l < nl - 1; ++l) {
+        const KnpAmgLevel& L = H.lv[l];
+        const double nl_ = (double)(l == 0 ? n0 * nf0 : L.n), nc_ = (double)L.n_coarse;
+        const bool mid = l >= 1 && H.cfused;
+        if (mid) {                                                  // Rt down, U up: operator + input gathered + output written
+            b += (H.blocked ? blocked(L.bRt, H.node_nf) : scalar(L.Rt_nnz, L.n_coarse)) + 8.0 * (nl_ + nc_);
+            b += (H.blocked ? blocked(L.bU, H.node_nf) : scalar(L.U_nnz, L.n)) + 8.0 * (nl_ + nc_ + nl_);
+        } else {                                                    // R down; S up with b, r, dinv and the output
+            b += (H.blocked ? blocked(L.bR, H.node_nf) : scalar(L.R_nnz, L.n_coarse)) + 8.0 * (nl_ + nc_);
+            b += (H.blocked ? blocked(L.bS, H.node_nf) : scalar(L.S_nnz, L.n)) + 8.0 * (nc_ + 4.0 * nl_);
+            if (l >= 1) b += (H.blocked ? blocked(L.bA, H.node_nf) : scalar(L.A_nnz, L.n)) + 8.0 * 3.0 * nl_;   // residual of the level
+        }
+    }
+    if (H.nc > 0) b += (double)H.nc * H.nc * (H.cinv_f ? 4.0 : 8.0) + 16.0 * H.nc;
+    return b;
+}
+int knp_get_traffic_model(const knp_ctx* ctx, double* out) {
+    if (!ctx || !out) return KNP_E_ARG;
+    const KnpHostGraph& g = ctx->g;
+    const double np_ = (double)ctx->n_pairs, no = (double)g.n_nodes_owned, ngp = (double)ctx->n_gp;
+    static const bool mf_off = getenv("KNP_SPMV_MF") && atoi(getenv("KNP_SPMV_MF")) == 0;
+    const bool mf = !mf_off && ctx->n_bc == 0 && ctx->d_pair_MK != nullptr;
+    // SpMV on A: per pair a_t (32 B), {M, K} (16 B) or a_c (48 B), the neighbour index; per node pointer, membrane index, side;
+    // per membrane pair 32 B + a column; x gathered through the caches is counted once (8 n_local), y written
+    out[0] = np_ * (32.0 + (mf ? 16.0 : 48.0) + 4.0) + no * (4.0 + 4.0 + 1.0) + 2.0 * ngp * (32.0 + 4.0) + 8.0 * ctx->n_dof_owned + 8.0 * ctx->n_dof_local;
+    double pc = 0.0;
+    if (ctx->pc_kind == KNP_PC_AMG) pc = cycle_bytes(ctx, ctx->hier[0]);
+    else if (ctx->pc_kind == KNP_PC_AMG_BT || ctx->pc_kind == KNP_PC_AMG_LT)
+        pc = cycle_bytes(ctx, ctx->hier[0]) + cycle_bytes(ctx, ctx->hier[1]) + np_ * 12.0 + no * 8.0 * 9.0;   // + the potential right-hand side (k_phi_rhs)
+    else if (ctx->pc_kind == KNP_PC_VBJACOBI) pc = no * 8.0 * (16.0 + 8.0);
+    out[1] = pc;
+    // matrix assembly per step (SURVEY B_asm_step in this layout): contribution lists (8 B value + 1 B slot), the cell means staged per node,
+    // a_t written (32 B per pair); + the membrane entries (facet matrices read, a_t slots updated, a_x written)
+    out[2] = (double)(ctx->n_tc > 0 ? ctx->n_tc : ctx->n_contrib) * 9.0 + (double)g.n_c * (4.0 * g.nv1 + 32.0 + 24.0 * g.nv1) + np_ * 32.0 + ngp * (64.0 + 48.0);
+    out[3] = no * (8.0 * 4.0 + 9.0) + np_ * (8.0 + 4.0 + 24.0) + (double)g.n_g * g.dim * 7.0 * 8.0 * 2.0;
+    out[4] = 8.0 * ctx->n_dof_owned;
     return KNP_OK;
 }
 int knp_get_stats(const knp_ctx* ctx, double* out) {

@@ -324,7 +324,7 @@ class OracleKNPEMI:
         self.gamma_tags = tuple(sorted(set(self.gamma_tag.tolist())))
         self.models = models if models is not None else [Model("passive", self.gamma_tags)]
         self.stimulus_tags = tuple(stimulus_tags) if stimulus_tags is not None else self.gamma_tags
-        self.stimulus_region = stimulus_region        # (axis, lo, hi) in scaled coords or None
+        self.stimulus_region = stimulus_region        # (axis, lo, hi) in scaled coords, a list of such triples, or None
         self.n_v = self.coords.shape[0]
         self.lay = build_layout(self.n_v, self.cells, self.cell_side)
         self.vol, self.G = cell_geometry(self.coords, self.cells)
@@ -373,9 +373,13 @@ class OracleKNPEMI:
         """Stimulus-region mask at facet quadrature points (ionic_model.py:557-586)."""
         if self.stimulus_region is None:
             return None
-        ax, lo, hi = self.stimulus_region
-        xq = np.einsum("qa,fa->fq", self.lamq, self.coords[self.fv][:, :, ax])
-        return ((xq > lo) & (xq < hi)).astype(np.float64)
+        # one (axis, lo, hi) or -- `multiple_stimulus_directions`, ionic_model.py:573-586 -- a list of them whose masks multiply
+        regions = [self.stimulus_region] if np.isscalar(self.stimulus_region[0]) else list(self.stimulus_region)
+        mask = 1.0
+        for ax, lo, hi in regions:
+            xq = np.einsum("qa,fa->fq", self.lamq, self.coords[self.fv][:, :, int(ax)])
+            mask = mask * ((xq > lo) & (xq < hi)).astype(np.float64)
+        return mask
 
     def _facet_mask_integral(self):
         m = self._mask_q()
@@ -786,7 +790,7 @@ class OracleKNPEMI:
         return x
 
     def run(self, time_steps, solver="lu_gauge", pc=None, rtol=1e-9, max_it=5000, log=None):
-        """solver: 'lu_gauge' (sparse LU, l2 gauge of the iterative path),
+        """solver: 'lu_gauge' (sparse LU, l2 gauge of the iterative path; 'lu_gauge_nd': with the nested-dissection ordering),
         'lu_pin' (sparse LU with one potential DoF pinned to 0 - a MUMPS-like gauge),
         'gmres' (PETSc-like left-preconditioned GMRES(30) with pc(P) callback factory)."""
         x = self.pack()
@@ -810,6 +814,8 @@ class OracleKNPEMI:
                 b = b - ns * (ns @ b)                                  # solver :333
             if solver == "lu_gauge":
                 x = solve_lu_gauge(A, b, ns, ns @ x)
+            elif solver == "lu_gauge_nd":                                  # same solve, nested-dissection ordering (long 3D runs)
+                x = solve_lu_gauge_nd(A, b, ns, ns @ x, self.node_coords())
             elif solver == "lu_pin":
                 x = solve_lu_pin(A, b, pin=self.n_dof - 1)
             elif solver == "gmres":

@@ -539,3 +539,34 @@ def test_direct_solver_config_against_reference_pins():
     assert abs(ne - pin_e) <= 1e-6 * pin_e, (ne, pin_e)
     x = s.backend.x.cpu().numpy()
     assert abs(x[3::4].sum()) <= 1e-12 * np.abs(x[3::4]).sum()
+
+
+@pytest.mark.parametrize("pc", ["hypre", "btcc"])
+def test_reassemble_P_rebuilds_the_preconditioner_every_step(pc):
+    """``ksp_settings: {reassemble_P: True}`` (reference KNPEMIx_solver.py:34-35, 405-406: re-assemble P with the current
+    concentrations every ``reassemble_N`` steps): the preconditioner matrix and its hierarchies are rebuilt inside the time loop,
+    the converged solution is that of the direct solve, and P really follows the fields."""
+    from CGx.KNPEMI.KNPEMIx_solver import SolverKNPEMI
+    from parity_utils import run_oracle
+    cfg = ci_config(N=16, steps=4, rtol=1e-11, pc=pc)
+    cfg["solver"]["ksp_settings"]["reassemble_P"] = True
+    p = make_problem(cfg)
+    s = SolverKNPEMI(p, solver_config=p.solver_config)
+    assert s.reassemble_P
+    seen = []
+    orig = s.assemble_preconditioner
+
+    def spy():
+        orig()
+        seen.append((id(s.hierarchy), s.backend.precond_csr().data.copy()))
+    s.assemble_preconditioner = spy
+    s.solve()
+    assert len(seen) == 4 and all(r > 0 for r in s.reasons)          # once before the loop + steps 2, 3, 4
+    assert len({h for h, _ in seen}) == 4                             # a new hierarchy every time
+    assert np.abs(seen[-1][1] - seen[0][1]).max() > 0                 # P moved with the concentrations
+    o = run_oracle(N=16, steps=4)
+    gam = (o.lay.node_i >= 0) & (o.lay.node_e >= 0)
+    assert np.allclose(p.phi_m_prev.numpy()[gam], o.phi_m[gam], rtol=1e-6, atol=0)
+    oi, oe = o.potential_norms()
+    ni, ne = s.potential_norms()
+    assert abs(ni - oi) <= 1e-6 * oi and abs(ne - oe) <= 1e-5 * oe

@@ -609,3 +609,43 @@ def test_independent_set_elimination_level_is_an_exact_block_factorisation():
     T1 = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(m, m))
     Lap = (sp.kron(sp.identity(m), T1) + sp.kron(T1, sp.identity(m)) + 1e-3 * sp.identity(m * m)).tocsr()
     assert amg.try_elimination_level(Lap, Lap.diagonal(), 1.0 / Lap.diagonal(), np.ones(m * m, bool), np.zeros(m * m, bool), 2.0, 2500, 1) is None
+
+
+def test_rise_and_decay_stimulus_expression():
+    """``HodgkinHuxley._add_stimulus(step=False)``: the gradually rising stimulus exp(-t/tau_decay) - exp(-t/tau_rise) (reference
+    KNPEMIx_ionic_model.py:553-555, parameters mixed_dim_problem.py:299-304).  The reference's own wiring always passes step=True
+    (KNPEMIx_problem.py:538-542), so no configuration reaches this branch; the expression itself -- compiled to the membrane
+    bytecode and interpreted -- is checked against the formula, with the area scaling and a region mask."""
+    from CGx.KNPEMI.KNPEMIx_ionic_model import HodgkinHuxley
+    from CGx.KNPEMI.KNPEMIx_problem import ProblemKNPEMI
+    cfg = ci_config(N=8, steps=2)
+    cfg["stimulus"].update({"tau_syn_rise": 2e-4, "tau_syn_decay": 1e-3})
+    cfg["stimulus_region"] = {"direction": "x", "range": [0.2, 0.6]}
+    p = ProblemKNPEMI(cfg)
+    assert p.tau_syn_rise == 2e-4 and p.tau_syn_decay == 1e-3
+    hh = HodgkinHuxley(p)
+    p.set_initial_conditions()
+    p.init_ionic_models([hh])
+    p.setup_variational_form()                      # defines the Nernst potentials ion["E"]
+    t = 7.3e-4
+    hh.t_mod.value = t
+    expr = hh._add_stimulus(0, step=False, range=p.stimulus_region_range, dir=p.stimulus_region_direction)
+    o = K.make_square(8, models=[K.Model("hh", (4,))])
+    o.stimulus_region = (0, 0.2e-6, 0.6e-6)
+    area = float((o.fmeas * o._facet_mask_integral()).sum())
+    assert abs(p.stimulus_area - area) <= 1e-12 * area
+    rng = np.random.default_rng(2)
+    nq = 50
+    phim = -0.07 + 0.01 * rng.random(nq)
+    na_i, na_e = 12.0 + rng.random(nq), 140.0 + rng.random(nq)
+    x = [1e-6 * rng.random(nq), 1e-6 * rng.random(nq)]
+    roles = {id(p.phi_m_prev): ("PHIM", 0)}
+    for j in range(3):
+        roles[id(p.wh[0][j])] = ("KI", j)
+        roles[id(p.wh[1][j])] = ("KE", j)
+    spec = fem.compile_program([expr, 0.0 * expr, 0.0 * expr], roles)
+    out = fem.interpret_program(spec, [na_i, 0 * na_i + 130, 0 * na_i + 5], [na_e, 0 * na_e + 4, 0 * na_e + 125], phim, [], x)
+    E_na = p.psi.value * np.log(na_e / na_i)
+    mask = ((x[0] > 0.2e-6) & (x[0] < 0.6e-6)) * 1.0
+    want = mask * 1e-9 * (np.exp(-t / 1e-3) - np.exp(-t / 2e-4)) * (phim - E_na) / area
+    assert np.max(np.abs(out[0] - want)) <= 1e-13 * np.max(np.abs(want)) and np.abs(want).max() > 0
