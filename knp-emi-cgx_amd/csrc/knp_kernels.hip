@@ -621,7 +621,7 @@ k_spmv(int n_rows, const int32_t* __restrict__ rp, const int32_t* __restrict__ c
 // MF ("matrix-free constants", the default without Dirichlet rows): the six time-invariant entries of a pair are not read (48 B) but
 // recomputed from its mass and stiffness constants (16 B, `mk`) with ac_entries -- bit-identical to the stored a_c, 35 % less
 // traffic per pair (52 instead of 84 bytes with the neighbour index).
-template <int G, int MODE, bool MF>
+template <int G, int MODE, bool MF, int U>
 __global__ void __launch_bounds__(NT)
 k_spmv_node(int n_list, const int32_t* __restrict__ nodes, const int32_t* __restrict__ pair_ptr, const int32_t* __restrict__ pair_col,
             const double* __restrict__ ac, const double2* __restrict__ mk, AcCoef coef_i, AcCoef coef_e,
@@ -638,25 +638,37 @@ k_spmv_node(int n_list, const int32_t* __restrict__ nodes, const int32_t* __rest
         const int p0 = pair_ptr[node];
         const int p1 = pair_ptr[node + 1];
         const AcCoef C = (MF && node_side[node]) ? coef_e : coef_i;      // pairs join nodes of the same side
-        for (int p = p0 + lane; p < p1; p += G) {
-            const int nb = pair_col[p];
-            const double2 xa = *reinterpret_cast<const double2*>(x + 4 * (size_t)nb);
-            const double2 xb = *reinterpret_cast<const double2*>(x + 4 * (size_t)nb + 2);
-            double2 c0, c1, c2;                                                                  // kk0 kk1 | kk2 phik0 | phik1 phik2
-            if (MF) {
-                const double2 m = mk[p];
-                ac_entries(C, m.x, m.y, c0, c1, c2);
-            } else {
-                c0 = *reinterpret_cast<const double2*>(ac + 6 * (size_t)p);
-                c1 = *reinterpret_cast<const double2*>(ac + 6 * (size_t)p + 2);
-                c2 = *reinterpret_cast<const double2*>(ac + 6 * (size_t)p + 4);
+        // U pairs in flight per lane (predicated: the surplus trips re-read the node's last pair and are dropped): the gathers of x
+        // are latency bound, two independent chains per lane hide more of it than twice the lanes with one chain each
+        for (int pb = p0 + lane; pb < p1; pb += U * G) {
+            int nb[U];
+            double2 xa[U], xb[U], mv[U], t0[U], t1[U], c0[U], c1[U], c2[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) nb[u] = pair_col[min(pb + u * G, p1 - 1)];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const size_t p = (size_t)min(pb + u * G, p1 - 1);
+                if (MF) {
+                    mv[u] = mk[p];
+                } else {
+                    c0[u] = *reinterpret_cast<const double2*>(ac + 6 * p);                      // kk0 kk1
+                    c1[u] = *reinterpret_cast<const double2*>(ac + 6 * p + 2);                  // kk2 phik0
+                    c2[u] = *reinterpret_cast<const double2*>(ac + 6 * p + 4);                  // phik1 phik2
+                }
+                t0[u] = *reinterpret_cast<const double2*>(at + 4 * p);                          // kphi0 kphi1
+                t1[u] = *reinterpret_cast<const double2*>(at + 4 * p + 2);                      // kphi2 phiphi
+                xa[u] = *reinterpret_cast<const double2*>(x + 4 * (size_t)nb[u]);
+                xb[u] = *reinterpret_cast<const double2*>(x + 4 * (size_t)nb[u] + 2);
             }
-            const double2 t0 = *reinterpret_cast<const double2*>(at + 4 * (size_t)p);        // kphi0 kphi1
-            const double2 t1 = *reinterpret_cast<const double2*>(at + 4 * (size_t)p + 2);    // kphi2 phiphi
-            y0 += c0.x * xa.x + t0.x * xb.y;
-            y1 += c0.y * xa.y + t0.y * xb.y;
-            y2 += c1.x * xb.x + t1.x * xb.y;
-            y3 += c1.y * xa.x + c2.x * xa.y + c2.y * xb.x + t1.y * xb.y;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (u > 0 && pb + u * G >= p1) break;
+                if (MF) ac_entries(C, mv[u].x, mv[u].y, c0[u], c1[u], c2[u]);
+                y0 += c0[u].x * xa[u].x + t0[u].x * xb[u].y;
+                y1 += c0[u].y * xa[u].y + t0[u].y * xb[u].y;
+                y2 += c1[u].x * xb[u].x + t1[u].x * xb[u].y;
+                y3 += c1[u].y * xa[u].x + c2[u].x * xa[u].y + c2[u].y * xb[u].x + t1[u].y * xb[u].y;
+            }
         }
         const int A = node_gv[node];
         if (A >= 0) {
@@ -707,10 +719,12 @@ static void launch_spmv_node(knp_ctx* ctx, int n_list, const int32_t* nodes, con
     const bool mf = !mf_off && ctx->n_bc == 0 && ctx->d_pair_MK != nullptr;
     const DevParams P = make_params(ctx);
     const AcCoef ci = ac_coef(P, 0), ce = ac_coef(P, 1);
-#define KNP_SPMV_NODE2(GG, MFF)                                                                                                        \
-    hipExtLaunchKernelGGL((k_spmv_node<GG, MODE, MFF>), dim3(nblocks((int64_t)n_list * GG)), dim3(NT), 0, ctx->stream, ev_a, ev_b, 0, n_list, nodes, \
+    static const int unroll = getenv("KNP_SPMV_UNROLL") ? atoi(getenv("KNP_SPMV_UNROLL")) : 2;
+#define KNP_SPMV_NODE3(GG, MFF, UU)                                                                                                    \
+    hipExtLaunchKernelGGL((k_spmv_node<GG, MODE, MFF, UU>), dim3(nblocks((int64_t)n_list * GG)), dim3(NT), 0, ctx->stream, ev_a, ev_b, 0, n_list, nodes, \
                           ctx->d_pair_ptr, ctx->d_pair_col, ctx->d_ac, ctx->d_pair_MK, ci, ce, ctx->d_at, ctx->d_node_gv, ctx->d_node_side, ctx->d_gptr, ctx->d_gx_i, \
                           ctx->d_gx_e, ctx->d_ax, x, b, y)
+#define KNP_SPMV_NODE2(GG, MFF) do { if (unroll >= 2) KNP_SPMV_NODE3(GG, MFF, 2); else KNP_SPMV_NODE3(GG, MFF, 1); } while (0)
 #define KNP_SPMV_NODE(GG) do { if (mf) KNP_SPMV_NODE2(GG, true); else KNP_SPMV_NODE2(GG, false); } while (0)
     switch (ctx->spmv_group) {
         case 4: KNP_SPMV_NODE(4); break;
@@ -720,6 +734,7 @@ static void launch_spmv_node(knp_ctx* ctx, int n_list, const int32_t* nodes, con
     }
 #undef KNP_SPMV_NODE
 #undef KNP_SPMV_NODE2
+#undef KNP_SPMV_NODE3
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2527,16 +2542,19 @@ int knp_create(knp_ctx** out, const knp_mesh_desc* mesh) {
     ctx->n_red_blocks = std::min(RED_BLOCKS, nblocks(ctx->n_dof_owned));
     {
         const double avg_deg = g.n_nodes_owned ? (double)ctx->n_pairs / g.n_nodes_owned : 1.0;
-        ctx->spmv_group = avg_deg <= 4.5 ? 4 : avg_deg <= 9.0 ? 8 : avg_deg <= 20.0 ? 16 : 32;
+        const int lanes_per_pair = avg_deg <= 4.5 ? 4 : avg_deg <= 9.0 ? 8 : avg_deg <= 20.0 ? 16 : 32;   // one lane per pair of a node
+        // SpMV on A: two pairs in flight per lane, half the lanes (measured on MI355X, rounds 2-3: 512^2 20.6 -> 19.9 us, cube 136^3
+        // 448 -> 411 us against one pair per lane)
+        ctx->spmv_group = std::max(4, lanes_per_pair / 2);
         const char* ef = getenv("KNP_ASM_FULL");
         ctx->asm_full = (ef && atoi(ef) > 0) ? 1 : 0;
         const char* e = getenv("KNP_SPMV");
         if (e && atoi(e) > 0) ctx->spmv_group = atoi(e);
-        ctx->asm_group = ctx->spmv_group;
+        ctx->asm_group = lanes_per_pair;
         const char* ea = getenv("KNP_ASM_GROUP");
         if (ea && atoi(ea) > 0 && ctx->asm_stage == 0) ctx->asm_group = atoi(ea);   // (the staged variant sized its LDS for the default)
         // the level-0 preconditioner kernels move half the bytes per node pair (fp32 P, no cross block): fewer lanes per node
-        ctx->pc_group = std::max(4, ctx->spmv_group / 2);
+        ctx->pc_group = std::max(4, lanes_per_pair / 2);
         const char* ep = getenv("KNP_PC_GROUP");
         if (ep && atoi(ep) > 0) ctx->pc_group = atoi(ep);
     }

@@ -1,4 +1,5 @@
-"""Developer tool (not part of the product or the tests); run on a GPU box from the repo root."""
+"""Developer tool (not part of the product or the tests); run on a GPU box from the repo root:  python tests/devtools/spmv_bench.py cube 64
+(KNP_SPMV = lanes per node, KNP_SPMV_UNROLL = pairs in flight per lane, KNP_SPMV_MF=0 reads the stored time-invariant entries)"""
 import sys, os, time; sys.path.insert(0,'tests'); import conftest
 import torch, numpy as np
 from parity_utils import *
@@ -12,6 +13,5 @@ e0.record()
 for _ in range(50): be.spmv(x,y)
 e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1)*1e3/50
-B = 12.0*be.nnz + 4*(be.n_dof_owned+1) + 16*be.n_dof_owned
-Bact = 8.0*be.nnz + 4*be.n_pairs + 4*(be.n_dof_owned+1) + 4*(be.n_nodes_owned+1) + 16*be.n_dof_owned
-print(os.environ.get("KNP_SPMV","node"), kind, N, "n", be.n_dof_owned, "nnz", be.nnz, f"{us:.1f} us  CSR-bytes GB/s {B/us/1e3:.0f}  node-format GB/s {Bact/us/1e3:.0f}", "checksum", float(y[:be.n_dof_owned].sum()))
+B = be.traffic_model()["spmv"]
+print("G", os.environ.get("KNP_SPMV","auto"), "U", os.environ.get("KNP_SPMV_UNROLL","2"), "MF", os.environ.get("KNP_SPMV_MF","1"), kind, N, "n", be.n_dof_owned, f"{us:.1f} us  {B/1e6:.0f} MB  {B/us/1e3:.0f} GB/s", "checksum", float(y[:be.n_dof_owned].sum()))
