@@ -166,6 +166,20 @@ class Stepper:
         return s.iterations[-1], s.reasons[-1]
 
 
+def comm_report(be, world, torch, dist):
+    """Which exchange path the ranks ended up on: the native peer-to-peer kernels (every plan passed its self-test against the
+    torch.distributed exchange on every rank) or the torch.distributed hooks; never measured on more than one device before the
+    driver's own multi-GPU run, so the line says what ran."""
+    if world == 1:
+        return {"path": "none (one GPU)", "device_count": torch.cuda.device_count()}
+    p2p = bool(getattr(be, "p2p_on", False))
+    plans = getattr(be, "_p2p_plans", {})
+    return {"path": "p2p (native kernels over peer-mapped mailboxes)" if p2p else f"hooks-{dist.get_backend()} (torch.distributed)",
+            "p2p_selftest": "passed on all ranks" if p2p else ("disabled (KNP_COMM)" if os.environ.get("KNP_COMM", "p2p") != "p2p" else "failed or unavailable: fell back on every rank"),
+            "p2p_plans": int(sum(1 for v in plans.values() if v is not None)), "backend": dist.get_backend(),
+            "device_count": torch.cuda.device_count(), "p2p_timeout_s": float(os.environ.get("KNP_P2P_TIMEOUT", "30"))}
+
+
 def spmv_bytes(be):
     """Bytes one SpMV on A must move: the node-structured kernel reads the matrix values (8 B per entry,
     pair-major) and a 4-B neighbour index per node PAIR instead of a 4-B column index per entry, the pair pointer, the
@@ -311,7 +325,8 @@ def main_case(args, world, rank, dist, torch):
                    "parallelism": f"dd{world}", "gmres_its_per_step": float(sum(run["its"])) / max(n_steps_timed, 1),
                    "converged_all": bool(all(r > 0 for r in run["reasons"])),
                    "phi_norms": [norms[0], norms[1]],
-                   "exchanges_per_gmres_iteration": per_it},
+                   "exchanges_per_gmres_iteration": per_it,
+                   "comm": comm_report(be, world, torch, dist)},
         "timing": {"reps": len(run["reps"]), "steps_per_rep": args.steps, "ms_per_step_each_rep": [1e3 * r / max(args.steps, 1) for r in run["reps"]],
                    "stat": "median of the repetitions" if len(run["reps"]) > 1 else "single bracket",
                    "timed_total_s": sum(run["reps"])},
@@ -355,15 +370,28 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("KNP_DIST_BACKEND", "nccl")      # "gloo": rehearsal with several ranks on one GPU
-        dev_index = local_rank % max(torch.cuda.device_count(), 1)
+        n_dev = torch.cuda.device_count()
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        if backend == "nccl" and n_dev < local_world:
+            # RCCL cannot put two ranks on one device: say so and stop instead of waiting in the rendezvous
+            print(f"bench.py: --gpus {world} needs {local_world} visible GPUs on this node, found {n_dev} "
+                  f"(KNP_DIST_BACKEND=gloo rehearses several ranks on one GPU)", file=sys.stderr, flush=True)
+            sys.exit(4)
+        dev_index = local_rank % max(n_dev, 1)
         torch.cuda.set_device(dev_index)
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        tmo = datetime.timedelta(seconds=float(os.environ.get("KNP_RENDEZVOUS_TIMEOUT", "180")))      # a missing rank ends the run, it does not hang it
+        try:
+            if backend == "nccl":
+                dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index), timeout=tmo)
+            else:
+                dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=tmo)
+        except Exception as exc:      # noqa: BLE001
+            print(f"bench.py: rank {rank}: rendezvous failed ({type(exc).__name__}: {exc})", file=sys.stderr, flush=True)
+            sys.exit(5)
     else:
         torch.cuda.set_device(0)
 

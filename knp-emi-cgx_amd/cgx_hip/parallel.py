@@ -181,7 +181,24 @@ def extract_local(coords, cells, cell_tags, gamma, gamma_tags, vertex_owner, ran
                      n_cells_global=int(n_cells_global if n_cells_global is not None else cells.shape[0]))
 
 
-def partition_mesh(coords, cells, cell_tags, gamma, gamma_tags, size, rank, intra_tags=None, max_modes=32) -> LocalMesh:
+def partition_mesh(coords, cells, cell_tags, gamma, gamma_tags, size, rank, intra_tags=None, max_modes=32, method=None) -> LocalMesh:
+    """Cut the global mesh for ``size`` ranks and return rank ``rank``'s part (owned vertices + one ghost-cell layer).
+    ``method``: ``rcb`` (weighted recursive coordinate bisection, the default for the generated lattices), ``slab``, or ``kway`` --
+    the multilevel k-way partition of the weighted nodal graph (cgx_hip/partition.py), the native counterpart of the graph
+    partitioner the reference inherits from DOLFINx (mixed_dim_problem.py:21,649,666) and the default for meshes READ from files.
+    ``KNP_PARTITION`` overrides.  If the graph partitioner fails the geometric one is used (never a hard error at setup)."""
+    method = os.environ.get("KNP_PARTITION", method or "rcb")
+    if size > 1 and method == "kway":
+        try:
+            from .partition import partition_mesh_vertices
+            owner = partition_mesh_vertices(coords, cells, size, None if intra_tags is None else np.isin(cell_tags, intra_tags))
+            lm = extract_local(coords, cells, cell_tags, gamma, gamma_tags, owner, rank)
+            if intra_tags is not None:
+                lm.defl = cut_component_modes(coords, cells, np.isin(cell_tags, intra_tags), gamma, owner, lm.l2g, max_modes)
+            return lm
+        except Exception as exc:      # noqa: BLE001
+            print(f"k-way graph partition failed ({type(exc).__name__}: {exc}); falling back to coordinate bisection", flush=True)
+            method = "rcb"
     wts = None
     if size > 1 and intra_tags is not None and os.environ.get("KNP_PARTITION_WEIGHTS", "1") != "0":
         # unknowns per vertex: one node per side the vertex touches (membrane vertices: two)
@@ -192,7 +209,7 @@ def partition_mesh(coords, cells, cell_tags, gamma, gamma_tags, size, rank, intr
         touch_e[np.asarray(cells)[~is_i].ravel()] = True
         wts = touch_i.astype(np.float64) + touch_e.astype(np.float64)
         wts[wts == 0.0] = 1.0
-    owner = vertex_partition(coords, size, weights=wts)
+    owner = vertex_partition(coords, size, method=method if method in ("rcb", "slab") else None, weights=wts)
     lm = extract_local(coords, cells, cell_tags, gamma, gamma_tags, owner, rank)
     if size > 1 and intra_tags is not None:
         lm.defl = cut_component_modes(coords, cells, np.isin(cell_tags, intra_tags), gamma, owner, lm.l2g, max_modes)

@@ -337,7 +337,10 @@ class MixedDimensionalProblem(ABC):
             gamma, gtags, gverts = meshmod.gamma_integration_entities(cells, cell_tags, self.intra_tags, self.extra_tag, facet_tags)
             keep = np.isin(gtags, self.gamma_tags)
             gamma, gtags = gamma[keep], gtags[keep]
-            lm = partition_mesh(coords, cells, cell_tags, gamma, gtags, self.comm.size, self.comm.rank, intra_tags=self.intra_tags)
+            # meshes read from files (reconstructions) are cut by the weighted graph partitioner, the generated lattices geometrically
+            generated = any(str(self.input_files["mesh_file"]).split("/")[-1].startswith(pfx) for pfx in ("square", "cube", "tissue"))
+            lm = partition_mesh(coords, cells, cell_tags, gamma, gtags, self.comm.size, self.comm.rank, intra_tags=self.intra_tags,
+                                method=self.config.get("partition", "rcb" if generated else "kway") if hasattr(self, "config") else None)
             lm.description = desc
         self.local_mesh = lm
         self.mesh = meshmod.Mesh(lm.coords, lm.cells)

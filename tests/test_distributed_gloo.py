@@ -36,12 +36,14 @@ def _worker(rank, size, port, kind, N, generator, q):
         comm = Comm()
         assert comm.size == size and comm.rank == rank
         # ---- global problem (every rank builds it to check against)
-        if generator == "partition":
+        if generator in ("partition", "kway"):
             gen = meshmod.create_unit_square if kind == "square" else meshmod.create_unit_cube
             c, t = gen(N)
             tags = meshmod.mark_subdomains_box(c, t)
             g, gt, _ = meshmod.gamma_integration_entities(t, tags, (1,), (2,))
-            lm = partition_mesh(c * 1e-6, t, tags, g, gt, size, rank)
+            # "kway": the multilevel graph partition of the weighted nodal graph (cgx_hip/partition.py) instead of coordinate bisection
+            lm = partition_mesh(c * 1e-6, t, tags, g, gt, size, rank, intra_tags=(1,) if generator == "kway" else None,
+                                method="kway" if generator == "kway" else None)
             og = K.OracleKNPEMI(c, t, tags, models=K.CI_MODELS(), mesh_conversion_factor=1e-6)
         else:
             gen = stacked_squares_local_mesh if kind == "square" else stacked_cubes_local_mesh
@@ -120,7 +122,7 @@ def _worker(rank, size, port, kind, N, generator, q):
         q.put((rank, traceback.format_exc()))
 
 
-@pytest.mark.parametrize("kind,N,generator", [("square", 12, "partition"), ("square", 8, "stacked"), ("cube", 4, "stacked")])
+@pytest.mark.parametrize("kind,N,generator", [("square", 12, "partition"), ("square", 8, "stacked"), ("cube", 4, "stacked"), ("square", 16, "kway")])
 def test_two_rank_halo_and_reductions(kind, N, generator):
     size = 2
     ctx = mp.get_context("spawn")

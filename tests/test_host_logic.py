@@ -649,3 +649,45 @@ def test_rise_and_decay_stimulus_expression():
     mask = ((x[0] > 0.2e-6) & (x[0] < 0.6e-6)) * 1.0
     want = mask * 1e-9 * (np.exp(-t / 1e-3) - np.exp(-t / 2e-4)) * (phim - E_na) / area
     assert np.max(np.abs(out[0] - want)) <= 1e-13 * np.max(np.abs(want)) and np.abs(want).max() > 0
+
+
+def test_multilevel_kway_partition_beats_coordinate_bisection():
+    """The native counterpart of the graph partitioner the reference inherits from DOLFINx (mixed_dim_problem.py:21,649,666):
+    multilevel k-way partition of the nodal graph, vertex weight = unknowns per vertex (membrane vertices carry two nodes), heavier
+    edges inside cells.  On the tissue lattice and on an irregular (Delaunay) mesh it is balanced within its 3 % band, deterministic,
+    covers every part, and cuts clearly less edge weight than the weighted coordinate bisection it replaces for meshes read from files."""
+    from scipy.spatial import Delaunay
+    from cgx_hip import partition as PT
+    cases = []
+    # (9 cells per direction: no bisection plane falls on an extracellular sheet, as it does by luck for 6 or 8 cells)
+    coords, cells, tags, _, _ = meshmod.load_mesh("tissue3d_37_9_w1.xdmf", "tissue3d_37_9_w1.xdmf", 1.0)
+    cases.append(("tissue", coords, cells, tags != 1, 0.75))
+    rng = np.random.default_rng(0)
+    pts = rng.random((20000, 2))
+    pts = pts[~((pts[:, 0] > 0.5) & (pts[:, 1] > 0.5))]                       # L-shaped domain
+    tri = Delaunay(pts).simplices
+    cen = pts[tri].mean(axis=1)
+    tri = tri[~((cen[:, 0] > 0.5) & (cen[:, 1] > 0.5))]
+    cen = pts[tri].mean(axis=1)
+    cases.append(("irregular", pts, tri, np.hypot(cen[:, 0] - 0.25, cen[:, 1] - 0.25) < 0.15, 0.95))
+    for name, X, T, intra, factor in cases:
+        vw = PT.mesh_vertex_weights(len(X), T, intra)
+        G = PT.nodal_graph(len(X), T, np.where(intra, 4.0, 1.0))
+        assert abs(G - G.T).max() == 0
+        for k in (5, 8):
+            own = PT.partition_mesh_vertices(X, T, k, intra)
+            assert np.array_equal(own, PT.partition_mesh_vertices(X, T, k, intra))          # deterministic
+            pw = np.bincount(own, weights=vw, minlength=k)
+            assert own.min() == 0 and own.max() == k - 1 and pw.min() > 0
+            assert pw.max() <= 1.035 * pw.mean(), (name, k, pw)
+            rcb = vertex_partition(X, k, weights=vw)
+            assert PT.edge_cut(G, own) <= factor * PT.edge_cut(G, rcb), (name, k, PT.edge_cut(G, own), PT.edge_cut(G, rcb))
+    # partition_mesh(method="kway") yields consistent local meshes: every vertex owned exactly once, ghost owners right
+    X, T, intra = cases[0][1], cases[0][2], cases[0][3]
+    tg = np.where(intra, 2, 1).astype(np.int32)
+    g, gt, _ = meshmod.gamma_integration_entities(T, tg, (2,), (1,))
+    seen = np.zeros(len(X), dtype=int)
+    for r in range(4):
+        lm = partition_mesh(X, T, tg, g, gt, 4, r, intra_tags=(2,), method="kway")
+        seen[lm.l2g[:lm.n_vertices_owned]] += 1
+    assert (seen == 1).all()
