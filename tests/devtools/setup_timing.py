@@ -19,9 +19,10 @@ be = s.backend
 t = time.perf_counter(); be.assemble_precond(); P = be.precond_csr(); tick("assemble P + fetch CSR", t)
 t = time.perf_counter(); Pk = amg.restrict_to_fields(P, (0, 1, 2)); Pp = amg.restrict_to_fields(P, (3,)); tick("field restriction", t)
 mode = sys.argv[2] if len(sys.argv) > 2 else "gpu"
-bh = (lambda M: amg_gpu.build_hierarchy(M, theta=s.amg_theta, coarse_size=s.amg_coarse_size, device=be.device)) if mode == "gpu" else (lambda M: amg.build_hierarchy(M, theta=s.amg_theta, coarse_size=s.amg_coarse_size))
-t = time.perf_counter(); hk = bh(Pk); tick(f"hierarchy ions ({mode})", t)
-t = time.perf_counter(); hp = bh(Pp); tick(f"hierarchy potential ({mode})", t)
+bh = (lambda M, nf=None: amg_gpu.build_hierarchy(M, theta=s.amg_theta, coarse_size=s.amg_coarse_size, device=be.device, node_fields=nf)) if mode == "gpu" else (lambda M, nf=None: amg.build_hierarchy(M, theta=s.amg_theta, coarse_size=s.amg_coarse_size, node_fields=nf))
+t = time.perf_counter(); hk = bh(Pk, (4, (0, 1, 2))); tick(f"hierarchy ions ({mode})", t)
+t = time.perf_counter(); be.set_coupled_potential(True); be.assemble_precond(); Pc = be.precond_phi_csr(); tick("coupled potential block: assemble + fetch", t)
+t = time.perf_counter(); hp = bh(Pc); tick(f"hierarchy potential ({mode})", t)
 print(hk.describe(), hp.describe())
 t = time.perf_counter(); amg.upload(be.lib, be.ctx, be.check, hk, 1, 1, 1, index=0); amg.upload(be.lib, be.ctx, be.check, hp, 1, 1, 1, index=1); tick("upload", t)
 print("n_dof", be.n_dof_owned, "total", sum(T.values()))
