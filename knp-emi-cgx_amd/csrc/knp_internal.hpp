@@ -220,6 +220,12 @@ struct knp_ctx {
     uint8_t* d_tc_slot = nullptr;
     int64_t n_tc = 0;
     int asm_stage = 0;    // cells per node the staged assembly reserves LDS for (0: gather per contribution)
+    // cell means computed inside the assembly's LDS staging (no k_cell_means pass): the node's neighbours' concentrations are read as
+    // 32-byte records from a node-indexed copy (d_knod, k_nodal_conc) and averaged per cell through d_ncv, the local neighbour
+    // index of every vertex of every cell of the node's list (cell vertex order: the same sums, bit for bit, as k_cell_means)
+    int asm_dmax = 0;     // > 0: fused form, LDS for this many neighbours per node
+    uint8_t* d_ncv = nullptr;
+    double* d_knod = nullptr;
     int32_t* d_fv = nullptr;
     double* d_fmeas = nullptr;
     int32_t* d_gamma_prog = nullptr;

@@ -232,22 +232,47 @@ k_assemble_nodes(int n_nodes, DevParams P, const int32_t* __restrict__ pair_ptr,
 // the group (24-byte records from the cell-mean array) instead of once per contribution (~72 per node: every cell feeds the
 // three off-diagonal pairs of the node it belongs to); a contribution is then 9 streamed bytes (K_ab(T), 1-byte slot) and three
 // LDS reads.  `cmax` = LDS slots reserved per group (>= the largest cell count of any owned node).
-template <bool PRECOND, bool TD_ONLY, int G>
-__global__ void __launch_bounds__(NT)
-k_assemble_nodes_staged(int n_nodes, DevParams P, int cmax, const int32_t* __restrict__ pair_ptr, const int32_t* __restrict__ pair_col,
-                        const uint8_t* __restrict__ node_side, const double* __restrict__ pair_M, const double* __restrict__ pair_K,
-                        const int32_t* __restrict__ contrib_ptr, const uint8_t* __restrict__ contrib_slot,
-                        const double* __restrict__ contrib_k, const int32_t* __restrict__ node_cell_ptr,
-                        const int32_t* __restrict__ node_cell, const double* __restrict__ cbar,
-                        double* __restrict__ at, double* __restrict__ ac) {
-    extern __shared__ double lds[];   // [NT / G][cmax][3]
-    const int node_raw = (blockIdx.x * NT + threadIdx.x) / G;
-    const int lane = threadIdx.x & (G - 1);
-    const bool live = node_raw < n_nodes;
-    const int node = live ? node_raw : n_nodes - 1;
-    double* mine = lds + (size_t)(threadIdx.x / G) * cmax * 3;
-    {
-        const int c0 = node_cell_ptr[node], c1 = node_cell_ptr[node + 1];
+// node-indexed copy of the concentrations of the node's own side: {k0, k1, k2, -} per node, one 32-byte record per gather
+__global__ void __launch_bounds__(NT) k_nodal_conc(int n_nodes, const int32_t* __restrict__ node_vertex, const uint8_t* __restrict__ node_side,
+                                                   FieldPtrs f, double* __restrict__ knod) {
+    const int n = blockIdx.x * NT + threadIdx.x;
+    if (n >= n_nodes) return;
+    const int v = node_vertex[n];
+    const int s = node_side[n];
+    const double a = (s ? f.ke[0] : f.ki[0])[v], b = (s ? f.ke[1] : f.ki[1])[v], c = (s ? f.ke[2] : f.ki[2])[v];
+    *reinterpret_cast<double2*>(knod + 4 * (size_t)n) = make_double2(a, b);
+    *reinterpret_cast<double2*>(knod + 4 * (size_t)n + 2) = make_double2(c, 0.0);
+}
+// Cell means of the node's same-side cells into LDS (`mine`, 3 doubles per cell of the node's list).  FUSED: from the neighbours'
+// nodal values (staged in `nbv` first: one 32-byte read per neighbour instead of a gathered 32-byte record per CELL plus the separate
+// k_cell_means pass that produced it -- 15 neighbours against 24 cells per node on the tetrahedral cubes), summed in the cell's
+// vertex order exactly like k_cell_means; otherwise from the precomputed records `cbar`.
+template <int G, bool FUSED>
+__device__ __forceinline__ void stage_cell_means(double* mine, double* nbv, int lane, int node, int p0, int deg, const int32_t* __restrict__ pair_col,
+                                                 const int32_t* __restrict__ node_cell_ptr, const int32_t* __restrict__ node_cell,
+                                                 const double* __restrict__ cbar, const uint8_t* __restrict__ ncv, const double* __restrict__ knod, int nv1) {
+    const int c0 = node_cell_ptr[node], c1 = node_cell_ptr[node + 1];
+    if (FUSED) {
+        for (int q = lane; q < deg; q += G) {
+            const size_t nb = (size_t)pair_col[p0 + q];
+            const double2 a = *reinterpret_cast<const double2*>(knod + 4 * nb);
+            const double c = knod[4 * nb + 2];
+            double* d = nbv + 3 * q;
+            d[0] = a.x; d[1] = a.y; d[2] = c;
+        }
+        __syncthreads();
+        const double inv = 1.0 / nv1;
+        for (int i = c0 + lane; i < c1; i += G) {
+            const uint8_t* __restrict__ lv = ncv + (size_t)nv1 * i;
+            double m0 = 0.0, m1 = 0.0, m2 = 0.0;
+            for (int a = 0; a < nv1; ++a) {
+                const double* u = nbv + 3 * (int)lv[a];
+                m0 += u[0]; m1 += u[1]; m2 += u[2];
+            }
+            double* d = mine + 3 * (i - c0);
+            d[0] = m0 * inv; d[1] = m1 * inv; d[2] = m2 * inv;
+        }
+    } else {
         for (int i = c0 + lane; i < c1; i += G) {
             const int cell = node_cell[i];
             const double2 c01 = *reinterpret_cast<const double2*>(cbar + (size_t)4 * cell);
@@ -257,8 +282,26 @@ k_assemble_nodes_staged(int n_nodes, DevParams P, int cmax, const int32_t* __res
         }
     }
     __syncthreads();
+}
+
+template <bool PRECOND, bool TD_ONLY, int G, bool FUSED>
+__global__ void __launch_bounds__(NT)
+k_assemble_nodes_staged(int n_nodes, DevParams P, int cmax, const int32_t* __restrict__ pair_ptr, const int32_t* __restrict__ pair_col,
+                        const uint8_t* __restrict__ node_side, const double* __restrict__ pair_M, const double* __restrict__ pair_K,
+                        const int32_t* __restrict__ contrib_ptr, const uint8_t* __restrict__ contrib_slot,
+                        const double* __restrict__ contrib_k, const int32_t* __restrict__ node_cell_ptr,
+                        const int32_t* __restrict__ node_cell, const double* __restrict__ cbar,
+                        double* __restrict__ at, double* __restrict__ ac,
+                        const uint8_t* __restrict__ ncv, const double* __restrict__ knod, int dmax, int nv1) {
+    extern __shared__ double lds[];   // [NT / G][cmax + dmax][3]
+    const int node_raw = (blockIdx.x * NT + threadIdx.x) / G;
+    const int lane = threadIdx.x & (G - 1);
+    const bool live = node_raw < n_nodes;
+    const int node = live ? node_raw : n_nodes - 1;
+    double* mine = lds + (size_t)(threadIdx.x / G) * (cmax + dmax) * 3;
     const int p0 = pair_ptr[node];
     const int deg = pair_ptr[node + 1] - p0;
+    stage_cell_means<G, FUSED>(mine, mine + 3 * cmax, lane, node, p0, deg, pair_col, node_cell_ptr, node_cell, cbar, ncv, knod, nv1);
     const int side = node_side[node];
     const double D0 = side ? P.De[0] : P.Di[0], D1 = side ? P.De[1] : P.Di[1], D2 = side ? P.De[2] : P.Di[2];
     const double f0 = P.dt * D0 * P.z[0] / P.psi, f1 = P.dt * D1 * P.z[1] / P.psi, f2 = P.dt * D2 * P.z[2] / P.psi;
@@ -321,32 +364,23 @@ k_assemble_nodes_staged(int n_nodes, DevParams P, int cmax, const int32_t* __res
 // Consecutive lanes then stream consecutive K_ab(T) values and slots (one 8-byte and one 1-byte load per lane and trip, each a
 // contiguous ~112-byte piece per node) where the pair-major lists put ~40 bytes between neighbouring lanes and made every load
 // walk ~20 cache lines per wave.  `meta[node]` = base | trips << 48 | (index of the self pair among the node's pairs, 255: none) << 56.
-template <bool PRECOND, bool TD_ONLY, int G>
+template <bool PRECOND, bool TD_ONLY, int G, bool FUSED>
 __global__ void __launch_bounds__(NT)
 k_assemble_nodes_tr(int n_nodes, DevParams P, int cmax, const int32_t* __restrict__ pair_ptr, const uint8_t* __restrict__ node_side,
                     const double* __restrict__ pair_M, const double* __restrict__ pair_K, const int64_t* __restrict__ meta,
                     const uint8_t* __restrict__ tslot, const double* __restrict__ tk, const int32_t* __restrict__ node_cell_ptr,
-                    const int32_t* __restrict__ node_cell, const double* __restrict__ cbar, double* __restrict__ at, double* __restrict__ ac) {
-    extern __shared__ double lds[];   // [NT / G][cmax][3]
+                    const int32_t* __restrict__ node_cell, const double* __restrict__ cbar, double* __restrict__ at, double* __restrict__ ac,
+                    const int32_t* __restrict__ pair_col, const uint8_t* __restrict__ ncv, const double* __restrict__ knod, int dmax, int nv1) {
+    extern __shared__ double lds[];   // [NT / G][cmax + dmax][3]
     const int node_raw = (blockIdx.x * NT + threadIdx.x) / G;
     const int lane = threadIdx.x & (G - 1);
     const bool live = node_raw < n_nodes;
     const int node = live ? node_raw : n_nodes - 1;
-    double* mine = lds + (size_t)(threadIdx.x / G) * cmax * 3;
+    double* mine = lds + (size_t)(threadIdx.x / G) * (cmax + dmax) * 3;
     const int64_t mt = meta[node];
     const int p0 = pair_ptr[node];
     const int deg = pair_ptr[node + 1] - p0;
-    {
-        const int c0 = node_cell_ptr[node], c1 = node_cell_ptr[node + 1];
-        for (int i = c0 + lane; i < c1; i += G) {
-            const int cell = node_cell[i];
-            const double2 c01 = *reinterpret_cast<const double2*>(cbar + (size_t)4 * cell);
-            const double c2 = cbar[(size_t)4 * cell + 2];
-            double* d = mine + 3 * (i - c0);
-            d[0] = c01.x; d[1] = c01.y; d[2] = c2;
-        }
-    }
-    __syncthreads();
+    stage_cell_means<G, FUSED>(mine, mine + 3 * cmax, lane, node, p0, deg, pair_col, node_cell_ptr, node_cell, cbar, ncv, knod, nv1);
     const int64_t base = mt & 0xffffffffffffLL;
     const int trips = (int)((mt >> 48) & 0xff);
     const int selfq = (int)((mt >> 56) & 0xff);
@@ -407,6 +441,14 @@ k_assemble_nodes_tr(int n_nodes, DevParams P, int cmax, const int32_t* __restric
     if (live && selfq < 255 && (selfq & (G - 1)) == lane) emit(p0 + selfq, -T0, -T1, -T2);
 }
 
+// what the volume assembly reads the previous concentrations from: the node-indexed copy (fused cell means) or the per-cell means
+static void launch_cell_means(knp_ctx* ctx, const FieldPtrs& f) {
+    const KnpHostGraph& g = ctx->g;
+    if (ctx->asm_dmax > 0)
+        hipLaunchKernelGGL(k_nodal_conc, dim3(nblocks(g.n_nodes)), dim3(NT), 0, ctx->stream, g.n_nodes, ctx->d_node_vertex, ctx->d_node_side, f, ctx->d_knod);
+    else
+        hipLaunchKernelGGL(k_cell_means, dim3(nblocks(g.n_c)), dim3(NT), 0, ctx->stream, g.n_c, g.nv1, ctx->d_cells, ctx->d_cell_side, f, ctx->d_cbar);
+}
 template <bool PRECOND, bool TD_ONLY>
 static void launch_assemble_nodes(knp_ctx* ctx, const DevParams& P, double* at, double* ac) {
     const KnpHostGraph& g = ctx->g;
@@ -414,10 +456,12 @@ static void launch_assemble_nodes(knp_ctx* ctx, const DevParams& P, double* at, 
     if (n <= 0) return;
     if (ctx->asm_stage > 0 && ctx->d_tc_meta) {   // staged + transposed contribution lists (default)
         const int cmax = ctx->asm_stage;
-#define KNP_ASMT(GG) hipLaunchKernelGGL((k_assemble_nodes_tr<PRECOND, TD_ONLY, GG>), dim3(nblocks((int64_t)n * GG)), dim3(NT),                        \
-                                        (size_t)(NT / GG) * cmax * 3 * sizeof(double), ctx->stream, n, P, cmax, ctx->d_pair_ptr, ctx->d_node_side,     \
+        const int dmax = ctx->asm_dmax, nv1 = g.nv1;
+#define KNP_ASMT2(GG, FF) hipLaunchKernelGGL((k_assemble_nodes_tr<PRECOND, TD_ONLY, GG, FF>), dim3(nblocks((int64_t)n * GG)), dim3(NT),                  \
+                                        (size_t)(NT / GG) * (cmax + dmax) * 3 * sizeof(double), ctx->stream, n, P, cmax, ctx->d_pair_ptr, ctx->d_node_side, \
                                         ctx->d_pair_M, ctx->d_pair_K, ctx->d_tc_meta, ctx->d_tc_slot, ctx->d_tc_k, ctx->d_node_cell_ptr,              \
-                                        ctx->d_node_cell, ctx->d_cbar, at, ac)
+                                        ctx->d_node_cell, ctx->d_cbar, at, ac, ctx->d_pair_col, ctx->d_ncv, ctx->d_knod, dmax, nv1)
+#define KNP_ASMT(GG) do { if (dmax > 0) KNP_ASMT2(GG, true); else KNP_ASMT2(GG, false); } while (0)
         switch (ctx->asm_group) {
             case 4: KNP_ASMT(4); break;
             case 8: KNP_ASMT(8); break;
@@ -425,14 +469,17 @@ static void launch_assemble_nodes(knp_ctx* ctx, const DevParams& P, double* at, 
             default: KNP_ASMT(32); break;
         }
 #undef KNP_ASMT
+#undef KNP_ASMT2
         return;
     }
     if (ctx->asm_stage > 0) {   // cell means staged in LDS (default)
         const int cmax = ctx->asm_stage;
-#define KNP_ASMS(GG) hipLaunchKernelGGL((k_assemble_nodes_staged<PRECOND, TD_ONLY, GG>), dim3(nblocks((int64_t)n * GG)), dim3(NT),                    \
-                                        (size_t)(NT / GG) * cmax * 3 * sizeof(double), ctx->stream, n, P, cmax, ctx->d_pair_ptr, ctx->d_pair_col,  \
+        const int dmax = ctx->asm_dmax, nv1 = g.nv1;
+#define KNP_ASMS2(GG, FF) hipLaunchKernelGGL((k_assemble_nodes_staged<PRECOND, TD_ONLY, GG, FF>), dim3(nblocks((int64_t)n * GG)), dim3(NT),              \
+                                        (size_t)(NT / GG) * (cmax + dmax) * 3 * sizeof(double), ctx->stream, n, P, cmax, ctx->d_pair_ptr, ctx->d_pair_col,  \
                                         ctx->d_node_side, ctx->d_pair_M, ctx->d_pair_K, ctx->d_contrib_ptr, ctx->d_contrib_slot, ctx->d_contrib_k, \
-                                        ctx->d_node_cell_ptr, ctx->d_node_cell, ctx->d_cbar, at, ac)
+                                        ctx->d_node_cell_ptr, ctx->d_node_cell, ctx->d_cbar, at, ac, ctx->d_ncv, ctx->d_knod, dmax, nv1)
+#define KNP_ASMS(GG) do { if (dmax > 0) KNP_ASMS2(GG, true); else KNP_ASMS2(GG, false); } while (0)
         switch (ctx->asm_group) {
             case 4: KNP_ASMS(4); break;
             case 8: KNP_ASMS(8); break;
@@ -440,6 +487,7 @@ static void launch_assemble_nodes(knp_ctx* ctx, const DevParams& P, double* at, 
             default: KNP_ASMS(32); break;
         }
 #undef KNP_ASMS
+#undef KNP_ASMS2
         return;
     }
 #define KNP_ASM(GG) hipLaunchKernelGGL((k_assemble_nodes<PRECOND, TD_ONLY, GG>), dim3(nblocks((int64_t)n * GG)), dim3(NT), 0, ctx->stream, n, P, ctx->d_pair_ptr, \
@@ -2425,6 +2473,41 @@ static int build_transposed_contribs(knp_ctx* ctx) {
     return KNP_OK;
 }
 
+// per (node, cell of its list) the local neighbour index of each of the cell's vertices, in the cell's vertex order (fused cell means)
+static int build_fused_cell_means(knp_ctx* ctx, const knp_mesh_desc* mesh, int G0) {
+    const KnpHostGraph& g = ctx->g;
+    const char* ef = getenv("KNP_ASM_FUSED_MEANS");
+    if (ef && atoi(ef) == 0) return KNP_OK;
+    const int no = g.n_nodes_owned, nv1 = g.nv1;
+    int dmax = 0;
+    for (int n = 0; n < no; ++n) dmax = std::max(dmax, g.pair_ptr[n + 1] - g.pair_ptr[n]);
+    const size_t lds = (size_t)(NT / G0) * (g.max_node_cells + dmax) * 3 * sizeof(double);
+    if (dmax <= 0 || dmax > 255 || lds > 64 * 1024 || g.node_cell.empty()) return KNP_OK;
+    std::vector<uint8_t> ncv((size_t)nv1 * g.node_cell.size());
+    int bad = 0;
+#pragma omp parallel for schedule(static) reduction(+ : bad)
+    for (int n = 0; n < no; ++n) {
+        const int32_t* pc = g.pair_col.data() + g.pair_ptr[n];
+        const int deg = g.pair_ptr[n + 1] - g.pair_ptr[n];
+        for (int i = g.node_cell_ptr[n]; i < g.node_cell_ptr[n + 1]; ++i) {
+            const int c = g.node_cell[i];
+            const int32_t* nodes = mesh->cell_side[c] ? g.node_e.data() : g.node_i.data();
+            for (int a = 0; a < nv1; ++a) {
+                const int nb = nodes[mesh->cells[(size_t)c * nv1 + a]];
+                const int32_t* it = std::lower_bound(pc, pc + deg, nb);
+                if (it == pc + deg || *it != nb) { ++bad; ncv[(size_t)nv1 * i + a] = 0; }
+                else ncv[(size_t)nv1 * i + a] = (uint8_t)(it - pc);
+            }
+        }
+    }
+    if (bad) return KNP_OK;   // a vertex of a node's cell that is not among its pairs: keep the separate cell-mean pass
+    KCHK(dev_upload(ctx, &ctx->d_ncv, ncv));
+    HIPCHK(hipMalloc((void**)&ctx->d_knod, (size_t)4 * std::max(g.n_nodes, 1) * sizeof(double)));
+    HIPCHK(hipMemset(ctx->d_knod, 0, (size_t)4 * std::max(g.n_nodes, 1) * sizeof(double)));
+    ctx->asm_dmax = dmax;
+    return KNP_OK;
+}
+
 int knp_create(knp_ctx** out, const knp_mesh_desc* mesh) {
     if (!out) return KNP_E_ARG;
     *out = nullptr;
@@ -2481,6 +2564,7 @@ int knp_create(knp_ctx** out, const knp_mesh_desc* mesh) {
             KCHK(dev_upload(ctx, &ctx->d_contrib_slot, g.contrib_slot));
             const char* et = getenv("KNP_ASM_TRANSPOSED");
             if (!(et && atoi(et) == 0)) KCHK(build_transposed_contribs(ctx));
+            KCHK(build_fused_cell_means(ctx, mesh, G0));
         } else {
             KCHK(dev_upload(ctx, &ctx->d_contrib_cell, g.contrib_cell));
         }
@@ -2601,7 +2685,7 @@ int knp_destroy(knp_ctx* ctx) {
     dev_free(ctx->d_pair_ptr); dev_free(ctx->d_pair_col); dev_free(ctx->d_pair_row);
     dev_free(ctx->d_pair_M); dev_free(ctx->d_pair_K); dev_free(ctx->d_pair_MK);
     dev_free(ctx->d_contrib_ptr); dev_free(ctx->d_contrib_cell); dev_free(ctx->d_contrib_k);
-    dev_free(ctx->d_node_cell_ptr); dev_free(ctx->d_node_cell); dev_free(ctx->d_contrib_slot);
+    dev_free(ctx->d_node_cell_ptr); dev_free(ctx->d_node_cell); dev_free(ctx->d_contrib_slot); dev_free(ctx->d_ncv); dev_free(ctx->d_knod);
     dev_free(ctx->d_tc_meta); dev_free(ctx->d_tc_k); dev_free(ctx->d_tc_slot);
     dev_free(ctx->d_fv); dev_free(ctx->d_fmeas); dev_free(ctx->d_gamma_prog); dev_free(ctx->d_qp); dev_free(ctx->d_qw);
     dev_free(ctx->d_gv_vertex); dev_free(ctx->d_gv_node_i); dev_free(ctx->d_gv_node_e); dev_free(ctx->d_node_gv);
@@ -2899,8 +2983,7 @@ static int assemble_matrix_on_stream(knp_ctx* ctx, const knp_fields* fields, boo
     const DevParams P = make_params(ctx);
     FieldPtrs f = make_fields(fields);
     ProfScope ps(ctx, 3);
-    hipLaunchKernelGGL(k_cell_means, dim3(nblocks(g.n_c)), dim3(NT), 0, ctx->stream, g.n_c, g.nv1, ctx->d_cells,
-                       ctx->d_cell_side, f, ctx->d_cbar);
+    launch_cell_means(ctx, f);
     // The (k,k) and (phi,k) blocks do not depend on the previous solution (SURVEY 3.2 obs. 1): after the first
     // assembly only the K[k_prev]-type and membrane entries are rewritten, unless KNP_ASM_FULL=1 asks for the
     // reference's behaviour (A.zeroEntries() + full re-assembly, KNPEMIx_solver.py:110-115).
@@ -3046,8 +3129,7 @@ int knp_assemble_precond(knp_ctx* ctx, const knp_fields* fields) {
     const DevParams P = make_params(ctx);
     FieldPtrs f = make_fields(fields);
     ProfScope ps(ctx, 3);
-    hipLaunchKernelGGL(k_cell_means, dim3(nblocks(g.n_c)), dim3(NT), 0, ctx->stream, g.n_c, g.nv1, ctx->d_cells,
-                       ctx->d_cell_side, f, ctx->d_cbar);
+    launch_cell_means(ctx, f);
     launch_assemble_nodes<true, false>(ctx, P, ctx->d_p_vals, nullptr);
     if (g.n_g > 0 && ctx->n_gp)
         hipLaunchKernelGGL((k_gamma_pairs<true>), dim3(nblocks(ctx->n_gp)), dim3(NT), 0, ctx->stream, ctx->n_gp, g.n_g, g.dim, P,

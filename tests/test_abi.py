@@ -53,3 +53,20 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".hpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "knpemi_oracle" not in src and "oracle/" not in src.replace("the oracle", ""), os.path.join(dirpath, f)
+
+
+def test_host_graph_builder_under_address_sanitizer():
+    """tools/asan/run.sh: the host-side graph builder (csrc/knp_setup.cpp) compiled with -fsanitize=address,undefined and run on a
+    small 2D and a small 3D mesh (GPU sanitizers are not available on the pool: CPU build only).  Skipped without libasan."""
+    import shutil
+    import subprocess
+    import pytest
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    probe = subprocess.run("echo 'int main(){return 0;}' | g++ -x c++ -fsanitize=address,undefined - -o /dev/null", shell=True, capture_output=True)
+    if probe.returncode != 0:
+        pytest.skip("libasan / libubsan not installed")
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "asan", "run.sh")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+    assert r.stdout.count("rc=0") == 2, r.stdout
