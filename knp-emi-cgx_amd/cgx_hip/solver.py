@@ -360,8 +360,8 @@ class SolverKNPEMI:
         arr = np.zeros((n_steps, 3))
         for k in range(n_steps):
             arr[k] = dts[4 * k:4 * k + 3]            # (the fourth interval of a step is unpack + output + the host's next-step work)
-        if self.comm.size > 1:
-            tt = torch.as_tensor(arr, device=self.backend.device)
+        if self.comm.size > 1:      # MAX over the ranks (device tensor under nccl, host tensor under gloo: same rule as Comm._reduce)
+            tt = torch.as_tensor(arr, device=self.backend.device if self.comm.backend == "nccl" else "cpu")
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
             arr = tt.cpu().numpy()
         for ode, asm, sol in arr:
