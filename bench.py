@@ -177,7 +177,9 @@ def comm_report(be, world, torch, dist):
     return {"path": "p2p (native kernels over peer-mapped mailboxes)" if p2p else f"hooks-{dist.get_backend()} (torch.distributed)",
             "p2p_selftest": "passed on all ranks" if p2p else ("disabled (KNP_COMM)" if os.environ.get("KNP_COMM", "p2p") != "p2p" else "failed or unavailable: fell back on every rank"),
             "p2p_plans": int(sum(1 for v in plans.values() if v is not None)), "backend": dist.get_backend(),
-            "device_count": torch.cuda.device_count(), "p2p_timeout_s": float(os.environ.get("KNP_P2P_TIMEOUT", "30"))}
+            "device_count": torch.cuda.device_count(), "p2p_timeout_s": float(os.environ.get("KNP_P2P_TIMEOUT", "30")),
+            "halo_overlap": {"spmv_interior_rows": os.environ.get("KNP_SPMV_SPLIT", "1") != "0" and p2p,
+                             "pc_level0_interior_rows": os.environ.get("KNP_PC_SPLIT", "1") != "0" and p2p}}
 
 
 def spmv_bytes(be):

@@ -8,7 +8,7 @@
 //   K2b k_gamma_pairs           gather of facet matrices into the CSR coupling entries
 //   K3  k_rhs                   mass * k_prev + membrane vectors -> b
 //   K4  k_spmv                  CSR SpMV, sub-wave per row, shuffle reduction
-//   K5  k_multi_dot / k_update_norm   classical Gram-Schmidt (fused multi-dot, fused update + norm)
+//   K5  k_multi_dot / k_update_scale  classical Gram-Schmidt (fused multi-dot; update + normalisation in one pass)
 //   K6  k_scale, k_lincomb
 //   K7  k_vbj_extract / k_vbj_apply   per-vertex 4x4 / 8x8 block-Jacobi (Schur form, no stored inverse)
 //   K8  k_phi_sum / k_phi_sub   null-space (gauge) projection
@@ -1144,12 +1144,17 @@ static void launch_restrict_first_t(hipStream_t st, int lanes, int n_rows, const
 // ------------------------------------------------------------------------------------------
 template <int G, int FM, typename VT>
 __global__ void __launch_bounds__(NT)
-k_l0_down(int n_nodes, const int32_t* __restrict__ pair_ptr, const int32_t* __restrict__ pair_col, const VT* __restrict__ pt,
-          const double* __restrict__ b, double c, double* __restrict__ r) {
-    const int node = (blockIdx.x * NT + threadIdx.x) / G;
+k_l0_down(int n_list, const int32_t* __restrict__ pair_ptr, const int32_t* __restrict__ pair_col, const VT* __restrict__ pt,
+          const double* __restrict__ b, double c, double* __restrict__ r, const int32_t* __restrict__ nodes = nullptr) {
+    // `nodes` (optional): the nodes to process -- interior / boundary split of the multi-GPU path (the halo of b runs next to the
+    // interior nodes, the nodes with a ghost neighbour follow the join)
+    const int idx = (blockIdx.x * NT + threadIdx.x) / G;
+    const int n_nodes = n_list;
+    const int node = (nodes && idx < n_list) ? nodes[idx] : idx;
+    const bool in_range = idx < n_list;
     const int lane = threadIdx.x & (G - 1);
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    if (node < n_nodes) {
+    if (in_range) {
         const int p0 = pair_ptr[node];
         const int deg = pair_ptr[node + 1] - p0;
         if (FM >= 2) {   // 4 B value + 4 B index + 8 B gather per pair: four predicated trips in flight per lane (see row_dot4)
@@ -1210,7 +1215,8 @@ k_l0_down(int n_nodes, const int32_t* __restrict__ pair_ptr, const int32_t* __re
         }
         if (FM != 1) s3 += __shfl_xor(s3, o, G);
     }
-    if (lane == 0 && node < n_nodes) {
+    (void)n_nodes;
+    if (lane == 0 && in_range) {
         if (FM == 2) {
             r[node] = b[node] - c * s3;
         } else if (FM == 3) {
@@ -1225,22 +1231,24 @@ k_l0_down(int n_nodes, const int32_t* __restrict__ pair_ptr, const int32_t* __re
     }
 }
 template <int FM, typename VT>
-static void launch_l0_down_t(hipStream_t st, int G, int n_nodes, const int32_t* pp, const int32_t* pc, const VT* pt, const double* b, double c, double* r) {
+static void launch_l0_down_t(hipStream_t st, int G, int n_nodes, const int32_t* pp, const int32_t* pc, const VT* pt, const double* b, double c, double* r,
+                             const int32_t* nodes = nullptr) {
     if (n_nodes <= 0) return;
     switch (G) {
-        case 2: hipLaunchKernelGGL((k_l0_down<2, FM, VT>), dim3(nblocks((int64_t)n_nodes * 2)), dim3(NT), 0, st, n_nodes, pp, pc, pt, b, c, r); break;
-        case 4: hipLaunchKernelGGL((k_l0_down<4, FM, VT>), dim3(nblocks((int64_t)n_nodes * 4)), dim3(NT), 0, st, n_nodes, pp, pc, pt, b, c, r); break;
-        case 8: hipLaunchKernelGGL((k_l0_down<8, FM, VT>), dim3(nblocks((int64_t)n_nodes * 8)), dim3(NT), 0, st, n_nodes, pp, pc, pt, b, c, r); break;
-        case 16: hipLaunchKernelGGL((k_l0_down<16, FM, VT>), dim3(nblocks((int64_t)n_nodes * 16)), dim3(NT), 0, st, n_nodes, pp, pc, pt, b, c, r); break;
-        default: hipLaunchKernelGGL((k_l0_down<32, FM, VT>), dim3(nblocks((int64_t)n_nodes * 32)), dim3(NT), 0, st, n_nodes, pp, pc, pt, b, c, r); break;
+        case 2: hipLaunchKernelGGL((k_l0_down<2, FM, VT>), dim3(nblocks((int64_t)n_nodes * 2)), dim3(NT), 0, st, n_nodes, pp, pc, pt, b, c, r, nodes); break;
+        case 4: hipLaunchKernelGGL((k_l0_down<4, FM, VT>), dim3(nblocks((int64_t)n_nodes * 4)), dim3(NT), 0, st, n_nodes, pp, pc, pt, b, c, r, nodes); break;
+        case 8: hipLaunchKernelGGL((k_l0_down<8, FM, VT>), dim3(nblocks((int64_t)n_nodes * 8)), dim3(NT), 0, st, n_nodes, pp, pc, pt, b, c, r, nodes); break;
+        case 16: hipLaunchKernelGGL((k_l0_down<16, FM, VT>), dim3(nblocks((int64_t)n_nodes * 16)), dim3(NT), 0, st, n_nodes, pp, pc, pt, b, c, r, nodes); break;
+        default: hipLaunchKernelGGL((k_l0_down<32, FM, VT>), dim3(nblocks((int64_t)n_nodes * 32)), dim3(NT), 0, st, n_nodes, pp, pc, pt, b, c, r, nodes); break;
     }
 }
 template <typename VT>
-static void launch_l0_down(hipStream_t st, int fm, int G, int n_nodes, const int32_t* pp, const int32_t* pc, const VT* pt, const double* b, double c, double* r) {
-    if (fm == 2) launch_l0_down_t<2, VT>(st, G, n_nodes, pp, pc, pt, b, c, r);
-    else if (fm == 3) launch_l0_down_t<3, VT>(st, G, n_nodes, pp, pc, pt, b, c, r);
-    else if (fm == 1) launch_l0_down_t<1, VT>(st, G, n_nodes, pp, pc, pt, b, c, r);
-    else launch_l0_down_t<0, VT>(st, G, n_nodes, pp, pc, pt, b, c, r);
+static void launch_l0_down(hipStream_t st, int fm, int G, int n_nodes, const int32_t* pp, const int32_t* pc, const VT* pt, const double* b, double c, double* r,
+                           const int32_t* nodes = nullptr) {
+    if (fm == 2) launch_l0_down_t<2, VT>(st, G, n_nodes, pp, pc, pt, b, c, r, nodes);
+    else if (fm == 3) launch_l0_down_t<3, VT>(st, G, n_nodes, pp, pc, pt, b, c, r, nodes);
+    else if (fm == 1) launch_l0_down_t<1, VT>(st, G, n_nodes, pp, pc, pt, b, c, r, nodes);
+    else launch_l0_down_t<0, VT>(st, G, n_nodes, pp, pc, pt, b, c, r, nodes);
 }
 
 // MODE 0: z[row] = x0 + c2 dinv r + S xc for the listed rows (rows == nullptr: all rows 0..n_act-1); x0 = xin[row] when xin is given,
@@ -1728,25 +1736,6 @@ __global__ void __launch_bounds__(NT) k_reduce_partials(int nb, const double* __
             *seq = seq_val;
         }
     }
-}
-
-// w -= sum_i h[i] V_i (and, with ns_scale != 0, w_phi -= h[m] * ns_scale: the gauge projection) ;
-// partial[blk] = sum w^2 over the block
-__global__ void __launch_bounds__(NT)
-k_update_norm(int n, int64_t ldv, int m, const double* __restrict__ V, const double* __restrict__ h,
-              double* __restrict__ w, double* __restrict__ partial, double ns_scale) {
-    __shared__ double sm[NT / 64];
-    double acc = 0.0;
-    const double mean = ns_scale != 0.0 ? h[m] * ns_scale : 0.0;
-    for (int e = blockIdx.x * NT + threadIdx.x; e < n; e += gridDim.x * NT) {
-        double we = w[e];
-        if ((e & 3) == 3) we -= mean;
-        for (int i = 0; i < m; ++i) we -= h[i] * V[(int64_t)i * ldv + e];
-        w[e] = we;
-        acc += we * we;
-    }
-    acc = block_sum(acc, sm);
-    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
 }
 
 // partial[blk] = sum a.b
@@ -3517,6 +3506,7 @@ int knp_amg_reset(knp_ctx* ctx, int32_t hier, int32_t n_levels, int32_t pre, int
     KnpAmgHier& H = ctx->hier[hier];
     free_hier(H);
     H.levels = n_levels; H.pre = pre; H.post = post; H.cheby = cheby;
+    ctx->side_ws = false;      // the new levels need their own second set of work vectors (ensure_side_ws)
     return KNP_OK;
 }
 // compact row list of a prolongator when a good part of its rows is empty
@@ -3941,16 +3931,34 @@ static double* amg_vcycle(knp_ctx* ctx, KnpAmgHier& H, int l, const double* b, d
         else launch_spmv_t<1, 0, double>(st, L.A_lanes, L.n, L.A_rp, L.A_ci, L.At_v, b, b, L.r);
     } else if (f0) {
         const double c0 = 1.0 / (0.5 * (1.1 + 0.1) * L.lambda_max);
-        if (L.dist && level_comm_on(ctx)) level_exchange(ctx, hidx, 0, 0, const_cast<double*>(b));
         const int nn = ctx->g.n_nodes_owned;
         const int fm = H.native0 == 1 ? 0 : H.native0 == 2 ? 1 : 3;
-        if (fm == 3) {
-            const int Gp = std::max(2, ctx->pc_group / 2);
-            if (H.pt_phi_f) launch_l0_down<float>(st, 3, Gp, nn, ctx->d_pair_ptr, ctx->d_pair_col, H.pt_phi_f, b, c0, L.r);
-            else launch_l0_down<double>(st, 3, Gp, nn, ctx->d_pair_ptr, ctx->d_pair_col, H.pt_phi, b, c0, L.r);
+        const int Gp = std::max(2, ctx->pc_group / 2);
+        auto down = [&](int n_list, const int32_t* nodes) {
+            if (fm == 3) {
+                if (H.pt_phi_f) launch_l0_down<float>(st, 3, Gp, n_list, ctx->d_pair_ptr, ctx->d_pair_col, H.pt_phi_f, b, c0, L.r, nodes);
+                else launch_l0_down<double>(st, 3, Gp, n_list, ctx->d_pair_ptr, ctx->d_pair_col, H.pt_phi, b, c0, L.r, nodes);
+            } else {
+                if (H.pt_f) launch_l0_down<float>(st, fm, Gp, n_list, ctx->d_pair_ptr, ctx->d_pair_col, H.pt_f, b, c0, L.r, nodes);
+                else launch_l0_down<double>(st, fm, Gp, n_list, ctx->d_pair_ptr, ctx->d_pair_col, H.pt, b, c0, L.r, nodes);
+            }
+        };
+        static const bool no_split = getenv("KNP_PC_SPLIT") && atoi(getenv("KNP_PC_SPLIT")) == 0;
+        if (L.dist && L.p2p_halo >= 0 && ctx->n_bnd > 0 && ctx->n_int > 0 && ctx->stream3 && !no_split) {
+            // The halo of the input runs on its own stream next to the nodes without a ghost neighbour; the others follow the join --
+            // the same overlap the SpMV on A has (same interior / boundary lists: P's graph is a subgraph of A's)
+            (void)hipEventRecord(ctx->ev_x, ctx->stream);
+            (void)hipStreamWaitEvent(ctx->stream3, ctx->ev_x, 0);
+            ctx->stream = ctx->stream3;
+            level_exchange(ctx, hidx, 0, 0, const_cast<double*>(b));
+            ctx->stream = st;
+            (void)hipEventRecord(ctx->ev_halo, ctx->stream3);
+            down(ctx->n_int, ctx->d_nodes_int);
+            (void)hipStreamWaitEvent(st, ctx->ev_halo, 0);
+            down(ctx->n_bnd, ctx->d_nodes_bnd);
         } else {
-            if (H.pt_f) launch_l0_down<float>(st, fm, std::max(2, ctx->pc_group / 2), nn, ctx->d_pair_ptr, ctx->d_pair_col, H.pt_f, b, c0, L.r);
-            else launch_l0_down<double>(st, fm, std::max(2, ctx->pc_group / 2), nn, ctx->d_pair_ptr, ctx->d_pair_col, H.pt, b, c0, L.r);
+            if (L.dist && level_comm_on(ctx)) level_exchange(ctx, hidx, 0, 0, const_cast<double*>(b));
+            down(nn, nullptr);
         }
     } else {
     for (int sw = 0; sw < H.pre; ++sw) { amg_smooth(ctx, H, l, b, &cur, bufA, bufB, zero, zero && first_done); zero = false; }
@@ -4223,6 +4231,7 @@ int knp_pc_setup(knp_ctx* ctx, int32_t kind) {
             const size_t nc = (size_t)L.n + (size_t)L.n_coarse;
             HIPCHK(hipMalloc((void**)&L.cat, nc * sizeof(double)));
             HIPCHK(hipMemsetAsync(L.cat, 0, nc * sizeof(double), ctx->stream));
+            ctx->side_ws = false;
         }
     }
     for (int h = 0; h < KNP_MAX_HIER; ++h) {   // level 0 in fused form inside the level-by-level cycle (distributed hierarchies)
@@ -4488,8 +4497,8 @@ static int ensure_side_ws(knp_ctx* ctx) {
         for (int l = 0; l < ctx->hier[h].levels; ++l) {
             KnpAmgLevel& L = ctx->hier[h].lv[l];
             const size_t n = (size_t)std::max(L.n_loc, L.n);
-            if (L.xs || n == 0) continue;
-            KCHK(zalloc(&L.xs, n)); KCHK(zalloc(&L.bs, n)); KCHK(zalloc(&L.rs, n)); KCHK(zalloc(&L.ds, n)); KCHK(zalloc(&L.r2s, n));
+            if (n == 0) continue;
+            if (!L.xs) { KCHK(zalloc(&L.xs, n)); KCHK(zalloc(&L.bs, n)); KCHK(zalloc(&L.rs, n)); KCHK(zalloc(&L.ds, n)); KCHK(zalloc(&L.r2s, n)); }
             if (L.cat && !L.cats) KCHK(zalloc(&L.cats, (size_t)L.n + (size_t)L.n_coarse));
         }
     const size_t nl = (size_t)std::max(ctx->n_dof_local, 1);

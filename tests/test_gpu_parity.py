@@ -276,6 +276,22 @@ def test_abi_argument_validation():
     # ... the slot layout carries restart + 2 values per reduction in 57 slots: 55 is the largest legal restart
     rc = lib.knp_gmres_solve(be.ctx, be.b.data_ptr(), be.x.data_ptr(), 1e-9, 1e-50, 10, 56, C.byref(its), C.byref(rn), C.byref(reason))
     assert rc == -1 and b"[1,55]" in lib.knp_last_error(be.ctx)
+    # entry points added in round 3
+    out1 = (C.c_double * 1)()
+    k = C.c_int32()
+    for _ in range(3):
+        assert lib.knp_timer_mark(be.ctx, 0) == 0
+    assert lib.knp_timer_pending(be.ctx) == 3
+    assert lib.knp_timer_read(be.ctx, 1, out1, C.byref(k)) == -1 and b"capacity" in lib.knp_last_error(be.ctx)      # 3 marks need 2 slots
+    out2 = (C.c_double * 2)()
+    assert lib.knp_timer_read(be.ctx, 2, out2, C.byref(k)) == 0 and k.value == 2 and out2[0] >= 0.0 and lib.knp_timer_pending(be.ctx) == 0
+    assert lib.knp_assemble_matrix_async(be.ctx, None) == -1
+    assert lib.knp_get_traffic_model(be.ctx, None) == -1
+    rp0 = (C.c_int32 * 2)(0, 0)
+    ci0 = (C.c_int32 * 1)(0)
+    v0 = (C.c_double * 1)(0.0)
+    assert lib.knp_amg_set_level_coarse_fused(be.ctx, 0, 0, 1, rp0, ci0, v0, 1, rp0, ci0, v0) == -1      # level 0 is never an intermediate level
+    assert lib.knp_get_precond_phi_csr(be2.ctx, rp0, ci0, v0) == -3 and b"not assembled" in lib.knp_last_error(be2.ctx)
     # Dirichlet dof out of range
     bad = (C.c_int32 * 1)(10 ** 8)
     assert lib.knp_set_dirichlet(be.ctx, 1, bad) == -1
