@@ -224,6 +224,7 @@ struct knp_ctx {
     // 32-byte records from a node-indexed copy (d_knod, k_nodal_conc) and averaged per cell through d_ncv, the local neighbour
     // index of every vertex of every cell of the node's list (cell vertex order: the same sums, bit for bit, as k_cell_means)
     int asm_dmax = 0;     // > 0: fused form, LDS for this many neighbours per node
+    int64_t n_node_cells = 0;   // total length of the per-node cell lists
     uint8_t* d_ncv = nullptr;
     double* d_knod = nullptr;
     int32_t* d_fv = nullptr;

@@ -2494,6 +2494,7 @@ static int build_fused_cell_means(knp_ctx* ctx, const knp_mesh_desc* mesh, int G
     HIPCHK(hipMalloc((void**)&ctx->d_knod, (size_t)4 * std::max(g.n_nodes, 1) * sizeof(double)));
     HIPCHK(hipMemset(ctx->d_knod, 0, (size_t)4 * std::max(g.n_nodes, 1) * sizeof(double)));
     ctx->asm_dmax = dmax;
+    ctx->n_node_cells = (int64_t)g.node_cell.size();
     return KNP_OK;
 }
 
@@ -4963,7 +4964,11 @@ int knp_get_traffic_model(const knp_ctx* ctx, double* out) {
     out[1] = pc;
     // matrix assembly per step (SURVEY B_asm_step in this layout): contribution lists (8 B value + 1 B slot), the cell means staged per node,
     // a_t written (32 B per pair); + the membrane entries (facet matrices read, a_t slots updated, a_x written)
-    out[2] = (double)(ctx->n_tc > 0 ? ctx->n_tc : ctx->n_contrib) * 9.0 + (double)g.n_c * (4.0 * g.nv1 + 32.0 + 24.0 * g.nv1) + np_ * 32.0 + ngp * (64.0 + 48.0);
+    // the previous concentrations: node-indexed copy + one 32-byte record per neighbour + the byte table of the cells' vertices
+    // (fused cell means), or the per-cell pass (connectivity, 3 (d+1) gathers, a 32-byte record written) + a record read per cell of a node
+    const double conc = ctx->asm_dmax > 0 ? (double)g.n_nodes * 56.0 + np_ * 36.0 + (double)ctx->n_node_cells * g.nv1
+                                          : (double)g.n_c * (4.0 * g.nv1 + 32.0 + 24.0 * g.nv1) + (double)ctx->n_node_cells * 36.0;
+    out[2] = (double)(ctx->n_tc > 0 ? ctx->n_tc : ctx->n_contrib) * 9.0 + conc + np_ * 32.0 + ngp * (64.0 + 48.0);
     out[3] = no * (8.0 * 4.0 + 9.0) + np_ * (8.0 + 4.0 + 24.0) + (double)g.n_g * g.dim * 7.0 * 8.0 * 2.0;
     out[4] = 8.0 * ctx->n_dof_owned;
     return KNP_OK;
