@@ -2551,6 +2551,7 @@ int knp_create(knp_ctx** out, const knp_mesh_desc* mesh) {
             ctx->asm_stage = g.max_node_cells;
             KCHK(dev_upload(ctx, &ctx->d_node_cell_ptr, g.node_cell_ptr));
             KCHK(dev_upload(ctx, &ctx->d_node_cell, g.node_cell));
+            ctx->n_node_cells = (int64_t)g.node_cell.size();
             KCHK(dev_upload(ctx, &ctx->d_contrib_slot, g.contrib_slot));
             const char* et = getenv("KNP_ASM_TRANSPOSED");
             if (!(et && atoi(et) == 0)) KCHK(build_transposed_contribs(ctx));
