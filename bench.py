@@ -282,6 +282,7 @@ def timed_run(case, args, world, dist, torch, steps, warmup, snapshot_at=None, a
     med = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
     setup = dict(solver.setup_breakdown)
     setup["amg_hierarchy_s"] = float(getattr(solver, "amg_setup_time", 0.0))      # part of preconditioner_setup_s
+    setup["amg_phases"] = {k: round(v, 3) for k, v in getattr(solver, "amg_setup_phases", {}).items()}
     setup["first_step_s"] = t_first
     setup["total_before_first_step_s"] = st.prepare_s
     return {"stepper": st, "elapsed": med, "reps": reps, "its": its_all, "reasons": reasons, "prof": prof, "stats": stats, "snap": snap,

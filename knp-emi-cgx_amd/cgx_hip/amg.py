@@ -442,8 +442,11 @@ def dense_pseudo_inverse(A: sp.spmatrix) -> np.ndarray:
     return np.linalg.pinv(D, rcond=1e-13, hermitian=bool(sym))
 
 
-def upload(lib, ctx, check, hier: Hierarchy, pre: int = 1, post: int = 1, cheby_degree: int = 2, index: int = 0):
-    """Hand the hierarchy to libknpemi_hip (host arrays are copied by the library)."""
+def upload(lib, ctx, check, hier: Hierarchy, pre: int = 1, post: int = 1, cheby_degree: int = 2, index: int = 0, level0_native: bool = False):
+    """Hand the hierarchy to libknpemi_hip (host arrays are copied by the library).  ``level0_native``: level 0 will run on the
+    library's own pair-major P (``knp_amg_use_native_level0`` modes 1-3), so its CSR -- the largest array of the hierarchy, 1.4 GB on
+    the 10^7-unknown cube -- is not shipped: an empty pattern takes its place (inverse diagonal, eigenvalue bound and the transfer
+    operators are what the cycle needs of that level)."""
     import ctypes as C
     i32p = C.POINTER(C.c_int32)
     f64p = C.POINTER(C.c_double)
@@ -465,9 +468,14 @@ def upload(lib, ctx, check, hier: Hierarchy, pre: int = 1, post: int = 1, cheby_
     keep = []
     for l, lv in enumerate(hier.levels):
         A = lv.A
-        rp = np.ascontiguousarray(A.indptr, dtype=np.int32)
-        ci = np.ascontiguousarray(A.indices, dtype=np.int32)
-        va = np.ascontiguousarray(A.data, dtype=np.float64)
+        if l == 0 and level0_native and len(hier.levels) > 1:
+            rp = np.zeros(A.shape[0] + 1, dtype=np.int32)
+            ci = np.zeros(1, dtype=np.int32)
+            va = np.zeros(1, dtype=np.float64)
+        else:
+            rp = np.ascontiguousarray(A.indptr, dtype=np.int32)
+            ci = np.ascontiguousarray(A.indices, dtype=np.int32)
+            va = np.ascontiguousarray(A.data, dtype=np.float64)
         dinv = np.ascontiguousarray(lv.dinv, dtype=np.float64)
         keep += [rp, ci, va, dinv]
         if lv.P is not None:

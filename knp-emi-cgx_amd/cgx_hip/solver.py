@@ -178,13 +178,22 @@ class SolverKNPEMI:
             self._pc_kind = _lib.PC_AMG_LT
         if self._pc_kind in (_lib.PC_AMG, _lib.PC_AMG_BT, _lib.PC_AMG_LT):
             tic = time.perf_counter()
+            phases = self.amg_setup_phases = {}
+            last = [tic]
+
+            def lap(name):      # where the one-off setup goes (bench.py: setup_s.amg_phases)
+                now = time.perf_counter()
+                phases[name] = phases.get(name, 0.0) + now - last[0]
+                last[0] = now
             be.check(be.lib.knp_amg_set_precision(be.ctx, 1 if self.amg_fp32 else 0))
             P = be.precond_csr()
+            lap("fetch_P_csr")
             if self.comm.size > 1 and os.environ.get("KNP_DIST_PC", "global") != "bj":
                 self._assemble_distributed_amg(P)
                 self.P_ = "device CSR (see Backend.precond_csr)"
                 return
-            P = P[:, :be.n_dof_owned].tocsr()          # per-rank block (block-Jacobi across GPUs)
+            own_block = lambda M: M if M.shape[1] == be.n_dof_owned else M[:, :be.n_dof_owned].tocsr()
+            P = own_block(P)                           # per-rank block (block-Jacobi across GPUs)
             host_build = lambda M, nf=None: amg.build_hierarchy(M, theta=self.amg_theta, coarse_size=self.amg_coarse_size, node_fields=nf,
                                                                 split_decoupled=self.amg_split_decoupled, smoother_degree=self.amg_cheby_degree)
             if str(self.amg_setup) == "gpu":
@@ -203,16 +212,25 @@ class SolverKNPEMI:
                 build = host_build
             if self._pc_kind == _lib.PC_AMG:
                 self.hierarchy = build(P, self.all_node_fields())
-                amg.upload(be.lib, be.ctx, be.check, self.hierarchy, self.amg_pre, self.amg_post, self.amg_cheby_degree, index=0)
+                lap("build_hierarchy")
+                amg.upload(be.lib, be.ctx, be.check, self.hierarchy, self.amg_pre, self.amg_post, self.amg_cheby_degree, index=0, level0_native=True)
                 be.check(be.lib.knp_amg_use_native_level0(be.ctx, 0, 1))   # level 0 is the library's own P
+                lap("upload")
                 self.hierarchies = [self.hierarchy]
             else:
-                hk = build(amg.restrict_to_fields(P, (0, 1, 2)), self.ion_node_fields())
-                hp = build(be.precond_phi_csr()[:, :be.n_dof_owned].tocsr() if self._coupled_phi else amg.restrict_to_fields(P, (3,)))
-                amg.upload(be.lib, be.ctx, be.check, hk, self.amg_pre, self.amg_post, self.amg_cheby_degree, index=0)
-                amg.upload(be.lib, be.ctx, be.check, hp, self.amg_pre, self.amg_post, self.amg_cheby_degree, index=1)
+                Pk = amg.restrict_to_fields(P, (0, 1, 2))
+                lap("restrict_ions")
+                hk = build(Pk, self.ion_node_fields())
+                lap("build_ion_hierarchy")
+                Pphi = own_block(be.precond_phi_csr()) if self._coupled_phi else amg.restrict_to_fields(P, (3,))
+                lap("potential_block")
+                hp = build(Pphi)
+                lap("build_potential_hierarchy")
+                amg.upload(be.lib, be.ctx, be.check, hk, self.amg_pre, self.amg_post, self.amg_cheby_degree, index=0, level0_native=True)
+                amg.upload(be.lib, be.ctx, be.check, hp, self.amg_pre, self.amg_post, self.amg_cheby_degree, index=1, level0_native=not self._coupled_phi)
                 be.check(be.lib.knp_amg_use_native_level0(be.ctx, 0, 2))   # ion fields of P
                 be.check(be.lib.knp_amg_use_native_level0(be.ctx, 1, 4 if self._coupled_phi else 3))   # potential: uploaded coupled block | P's
+                lap("upload")
                 self.hierarchies = [hk, hp]
                 self.hierarchy = hk
             self.amg_setup_time = time.perf_counter() - tic

@@ -4148,6 +4148,10 @@ static void amg_cycle_fused(knp_ctx* ctx, KnpAmgHier& H, const double* b, double
 static int check_hier(knp_ctx* ctx, int h) {
     KnpAmgHier& H = ctx->hier[h];
     if (H.levels < 1 || H.lv[0].n != ctx->n_dof_owned) { ctx->err = "AMG hierarchy " + std::to_string(h) + " not supplied"; return KNP_E_STATE; }
+    if (H.native0 == 0 && H.lv[0].A_nnz == 0 && H.levels > 1) {   // uploaded with an empty level-0 pattern (the library's own P was to serve as level 0)
+        ctx->err = "AMG hierarchy " + std::to_string(h) + ": level 0 has no operator (uploaded for knp_amg_use_native_level0, which is off)";
+        return KNP_E_STATE;
+    }
     for (int l = 0; l < H.levels - 1; ++l) {
         const int expect = H.lv[l].repl_n > 0 ? H.lv[l + 1].n : H.lv[l + 1].n_loc;   // rows of R = coarse local size
         if (H.lv[l].n_coarse != expect) { ctx->err = "AMG level sizes inconsistent"; return KNP_E_STATE; }
