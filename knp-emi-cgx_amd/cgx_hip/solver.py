@@ -85,6 +85,7 @@ class SolverKNPEMI:
     amg_fp32 = True        # mixed-precision preconditioner storage (operators fp32, vectors/Krylov fp64)
     amg_node_sync = True   # ion hierarchy: aggregate NODES once, all three ion fields share aggregates and sparsity patterns
     amg_split_decoupled = True   # unknowns without off-diagonal entries on a level are solved by its smoother, not coarsened further
+    amg_agg_distance = "2"  # aggregation distance per level of the first hierarchy (ions / all fields), last entry repeated: "2" | "1,2" | "1"
     _b_is_final = False
     btcc_coupled_phi = True  # btcc on one GPU: potential hierarchy on the potential block of A (both sides + membrane coupling), not on P's
     amg_setup = "gpu"      # where the hierarchy is built: "gpu" (torch sparse products, cgx_hip/amg_gpu.py) | "host" (SciPy)
@@ -117,7 +118,7 @@ class SolverKNPEMI:
             if "gmres_restart" in ks: self.gmres_restart = int(ks["gmres_restart"])
             if "strict" in ks: self.strict = bool(ks["strict"])
             for k in ("amg_theta", "amg_cheby_degree", "amg_pre", "amg_post", "amg_coarse_size", "amg_replicate_below", "amg_fp32", "amg_setup", "amg_node_sync", "amg_split_decoupled",
-                      "btcc_coupled_phi"):
+                      "btcc_coupled_phi", "amg_agg_distance"):
                 if k in ks: setattr(self, k, type(getattr(self, k))(ks[k]))
         if self.ksp_type != "gmres":
             raise NotImplementedError(f"ksp_type '{self.ksp_type}': only 'gmres' is implemented natively.")
@@ -194,8 +195,11 @@ class SolverKNPEMI:
                 return
             own_block = lambda M: M if M.shape[1] == be.n_dof_owned else M[:, :be.n_dof_owned].tocsr()
             P = own_block(P)                           # per-rank block (block-Jacobi across GPUs)
+            # aggregation distance: the first hierarchy (the one built with node fields) may use smaller aggregates on its finest levels
+            dist_of = lambda nf: [int(v) for v in str(self.amg_agg_distance).replace(" ", "").split(",") if v] if nf is not None else 2
             host_build = lambda M, nf=None: amg.build_hierarchy(M, theta=self.amg_theta, coarse_size=self.amg_coarse_size, node_fields=nf,
-                                                                split_decoupled=self.amg_split_decoupled, smoother_degree=self.amg_cheby_degree)
+                                                                split_decoupled=self.amg_split_decoupled, smoother_degree=self.amg_cheby_degree,
+                                                                agg_distance=dist_of(nf))
             if str(self.amg_setup) == "gpu":
                 from . import amg_gpu
 
@@ -204,7 +208,8 @@ class SolverKNPEMI:
                     # products are not usable on this installation, build the same hierarchy with SciPy
                     try:
                         return amg_gpu.build_hierarchy(M, theta=self.amg_theta, coarse_size=self.amg_coarse_size, device=be.device, node_fields=nf,
-                                                       split_decoupled=self.amg_split_decoupled, smoother_degree=self.amg_cheby_degree)
+                                                       split_decoupled=self.amg_split_decoupled, smoother_degree=self.amg_cheby_degree,
+                                                       agg_distance=dist_of(nf))
                     except (RuntimeError, NotImplementedError) as exc:
                         self.print(f"device-side AMG setup unavailable ({type(exc).__name__}: {exc}); using the host setup")
                         return host_build(M, nf)

@@ -248,7 +248,7 @@ struct knp_ctx {
     bool have_A = false, have_P = false, have_cc = false;
     // work arrays
     double* d_cbar = nullptr;   // [3*n_c]
-    double* d_fmat = nullptr;   // [6*npk*n_g]
+    double* d_fmat = nullptr;   // [n_g][npk][6]: facet-major 48-byte records
     double* d_fvec = nullptr;   // [7*dim*n_g]
     // programs
     std::vector<KnpProgram> progs;

@@ -71,52 +71,116 @@ std::string kernel_source_path() {
 
 std::string reg(int r) { return "r" + std::to_string(r); }
 
-// one statement per instruction; mirrors run_program() in knp_gamma_facets.inc case by case
-bool emit_program(std::ostringstream& o, int id, const KnpProgram& p) {
-    o << "__device__ __forceinline__ void knp_prog_" << id
-      << "(const double* __restrict__ C, const double* ki, const double* ke, double phim, const double* aux, const double* xq, double* I) {\n";
-    if (p.n_regs > 0) {
-        o << "    double ";
-        for (int r = 0; r < p.n_regs; ++r) o << (r ? ", " : "") << reg(r) << " = 0.0";
-        o << ";\n";
+constexpr int KNP_JIT_UNIFORMS = 16;   // values a program may compute once per thread instead of once per quadrature point
+
+// one statement of straight-line code for instruction (op, d, a, b); false: unknown opcode
+bool emit_statement(std::ostringstream& o, int op, int d, int a, int b) {
+    const std::string D = reg(d), A = reg(a), B = reg(b);
+    switch (op) {
+        case KNP_OP_CONST: o << D << " = C[" << a << "];"; break;
+        case KNP_OP_KI: o << D << " = ki[" << a << "];"; break;
+        case KNP_OP_KE: o << D << " = ke[" << a << "];"; break;
+        case KNP_OP_PHIM: o << D << " = phim;"; break;
+        case KNP_OP_AUX: o << D << " = aux[" << a << "];"; break;
+        case KNP_OP_X: o << D << " = xq[" << a << "];"; break;
+        case KNP_OP_ADD: o << D << " = " << A << " + " << B << ";"; break;
+        case KNP_OP_SUB: o << D << " = " << A << " - " << B << ";"; break;
+        case KNP_OP_MUL: o << D << " = " << A << " * " << B << ";"; break;
+        case KNP_OP_DIV: o << D << " = " << A << " / " << B << ";"; break;
+        case KNP_OP_NEG: o << D << " = -" << A << ";"; break;
+        case KNP_OP_POW: o << D << " = pow(" << A << ", " << B << ");"; break;
+        case KNP_OP_LN: o << D << " = log(" << A << ");"; break;
+        case KNP_OP_EXP: o << D << " = exp(" << A << ");"; break;
+        case KNP_OP_SQRT: o << D << " = sqrt(" << A << ");"; break;
+        case KNP_OP_MAX: o << D << " = fmax(" << A << ", " << B << ");"; break;
+        case KNP_OP_MIN: o << D << " = fmin(" << A << ", " << B << ");"; break;
+        case KNP_OP_ABS: o << D << " = fabs(" << A << ");"; break;
+        case KNP_OP_LT: o << D << " = " << A << " < " << B << " ? 1.0 : 0.0;"; break;
+        case KNP_OP_GT: o << D << " = " << A << " > " << B << " ? 1.0 : 0.0;"; break;
+        case KNP_OP_LE: o << D << " = " << A << " <= " << B << " ? 1.0 : 0.0;"; break;
+        case KNP_OP_GE: o << D << " = " << A << " >= " << B << " ? 1.0 : 0.0;"; break;
+        case KNP_OP_EQ: o << D << " = " << A << " == " << B << " ? 1.0 : 0.0;"; break;
+        case KNP_OP_AND: o << D << " = (" << A << " != 0.0 && " << B << " != 0.0) ? 1.0 : 0.0;"; break;
+        case KNP_OP_OR: o << D << " = (" << A << " != 0.0 || " << B << " != 0.0) ? 1.0 : 0.0;"; break;
+        case KNP_OP_NOT: o << D << " = " << A << " != 0.0 ? 0.0 : 1.0;"; break;
+        case KNP_OP_SEL: o << D << " = " << A << " != 0.0 ? " << B << " : " << D << ";"; break;
+        case KNP_OP_OUT: o << "I[" << a << "] += " << B << ";"; break;
+        case KNP_OP_MOV: o << D << " = " << A << ";"; break;
+        case KNP_OP_POWI: o << D << " = powi_d(" << A << ", " << b << ");"; break;
+        default: return false;
     }
+    return true;
+}
+
+// which source registers an instruction reads (SEL also reads its destination)
+void sources(int op, int d, int a, int b, int out[3], int& n) {
+    n = 0;
+    switch (op) {
+        case KNP_OP_CONST: case KNP_OP_KI: case KNP_OP_KE: case KNP_OP_PHIM: case KNP_OP_AUX: case KNP_OP_X: break;
+        case KNP_OP_NEG: case KNP_OP_LN: case KNP_OP_EXP: case KNP_OP_SQRT: case KNP_OP_ABS: case KNP_OP_NOT: case KNP_OP_MOV: case KNP_OP_POWI:
+            out[n++] = a; break;
+        case KNP_OP_OUT: out[n++] = b; break;
+        case KNP_OP_SEL: out[n++] = a; out[n++] = b; out[n++] = d; break;
+        default: out[n++] = a; out[n++] = b; break;
+    }
+}
+
+// Two functions per program, one statement per instruction (mirrors run_program() in knp_gamma_facets.inc case by case):
+//   knp_prog_<id>_pre(C, U)  -- the instructions whose operands trace back to the constant table only (psi / z_k, exp(-t / a_syn), ...:
+//                               a division or an exponential each, the same for every quadrature point), executed once per thread;
+//   knp_prog_<id>(C, U, ...) -- the program per quadrature point, where such an instruction is a read of U.
+// The compiler does not hoist them by itself out of the unrolled point loop (every copy re-did its four divisions and the exponential).
+bool emit_program(std::ostringstream& o, int id, const KnpProgram& p) {
+    const int nr = std::max(p.n_regs, 1);
+    std::vector<char> uni((size_t)nr, 0);          // register currently holds a constant-only value
+    std::vector<int> slot((size_t)p.n_instr, -1);  // instruction -> index into U (computed instructions only; CONST loads stay loads)
+    int n_slots = 0;
     for (int i = 0; i < p.n_instr; ++i) {
         const int op = p.h_code[4 * i], d = p.h_code[4 * i + 1], a = p.h_code[4 * i + 2], b = p.h_code[4 * i + 3];
-        const std::string D = reg(d), A = reg(a), B = reg(b);
-        o << "    ";
-        switch (op) {
-            case KNP_OP_CONST: o << D << " = C[" << a << "];"; break;
-            case KNP_OP_KI: o << D << " = ki[" << a << "];"; break;
-            case KNP_OP_KE: o << D << " = ke[" << a << "];"; break;
-            case KNP_OP_PHIM: o << D << " = phim;"; break;
-            case KNP_OP_AUX: o << D << " = aux[" << a << "];"; break;
-            case KNP_OP_X: o << D << " = xq[" << a << "];"; break;
-            case KNP_OP_ADD: o << D << " = " << A << " + " << B << ";"; break;
-            case KNP_OP_SUB: o << D << " = " << A << " - " << B << ";"; break;
-            case KNP_OP_MUL: o << D << " = " << A << " * " << B << ";"; break;
-            case KNP_OP_DIV: o << D << " = " << A << " / " << B << ";"; break;
-            case KNP_OP_NEG: o << D << " = -" << A << ";"; break;
-            case KNP_OP_POW: o << D << " = pow(" << A << ", " << B << ");"; break;
-            case KNP_OP_LN: o << D << " = log(" << A << ");"; break;
-            case KNP_OP_EXP: o << D << " = exp(" << A << ");"; break;
-            case KNP_OP_SQRT: o << D << " = sqrt(" << A << ");"; break;
-            case KNP_OP_MAX: o << D << " = fmax(" << A << ", " << B << ");"; break;
-            case KNP_OP_MIN: o << D << " = fmin(" << A << ", " << B << ");"; break;
-            case KNP_OP_ABS: o << D << " = fabs(" << A << ");"; break;
-            case KNP_OP_LT: o << D << " = " << A << " < " << B << " ? 1.0 : 0.0;"; break;
-            case KNP_OP_GT: o << D << " = " << A << " > " << B << " ? 1.0 : 0.0;"; break;
-            case KNP_OP_LE: o << D << " = " << A << " <= " << B << " ? 1.0 : 0.0;"; break;
-            case KNP_OP_GE: o << D << " = " << A << " >= " << B << " ? 1.0 : 0.0;"; break;
-            case KNP_OP_EQ: o << D << " = " << A << " == " << B << " ? 1.0 : 0.0;"; break;
-            case KNP_OP_AND: o << D << " = (" << A << " != 0.0 && " << B << " != 0.0) ? 1.0 : 0.0;"; break;
-            case KNP_OP_OR: o << D << " = (" << A << " != 0.0 || " << B << " != 0.0) ? 1.0 : 0.0;"; break;
-            case KNP_OP_NOT: o << D << " = " << A << " != 0.0 ? 0.0 : 1.0;"; break;
-            case KNP_OP_SEL: o << D << " = " << A << " != 0.0 ? " << B << " : " << D << ";"; break;
-            case KNP_OP_OUT: o << "I[" << a << "] += " << B << ";"; break;
-            case KNP_OP_MOV: o << D << " = " << A << ";"; break;
-            case KNP_OP_POWI: o << D << " = powi_d(" << A << ", " << b << ");"; break;
-            default: return false;
+        int src[3], ns = 0;
+        sources(op, d, a, b, src, ns);
+        if (op == KNP_OP_OUT) continue;
+        bool u = op == KNP_OP_CONST;
+        if (!u && ns > 0) {
+            u = true;
+            for (int k = 0; k < ns; ++k) u = u && src[k] >= 0 && src[k] < nr && uni[(size_t)src[k]];
+            if (u) {
+                if (n_slots < KNP_JIT_UNIFORMS) slot[(size_t)i] = n_slots++;
+                else u = false;                       // table full: computed per point as before (operands are still available there)
+            }
         }
+        if (d >= 0 && d < nr) uni[(size_t)d] = u;
+    }
+    auto declare = [&](std::ostringstream& s) {
+        if (p.n_regs > 0) {
+            s << "    double ";
+            for (int r = 0; r < p.n_regs; ++r) s << (r ? ", " : "") << reg(r) << " = 0.0";
+            s << ";\n";
+        }
+    };
+    // the prologue replays the constant-only part of the program (every CONST load and every instruction with a slot)
+    o << "__device__ __forceinline__ void knp_prog_" << id << "_pre(const double* __restrict__ C, double* U) {\n";
+    if (n_slots > 0) {
+        declare(o);
+        std::fill(uni.begin(), uni.end(), 0);
+        for (int i = 0; i < p.n_instr; ++i) {
+            const int op = p.h_code[4 * i], d = p.h_code[4 * i + 1], a = p.h_code[4 * i + 2], b = p.h_code[4 * i + 3];
+            if (op != KNP_OP_CONST && slot[(size_t)i] < 0) continue;
+            o << "    ";
+            if (!emit_statement(o, op, d, a, b)) return false;
+            if (slot[(size_t)i] >= 0) o << " U[" << slot[(size_t)i] << "] = " << reg(d) << ";";
+            o << "\n";
+        }
+    }
+    o << "}\n\n";
+    o << "__device__ __forceinline__ void knp_prog_" << id
+      << "(const double* __restrict__ C, const double* U, const double* ki, const double* ke, double phim, const double* aux, const double* xq, double* I) {\n";
+    declare(o);
+    for (int i = 0; i < p.n_instr; ++i) {
+        const int op = p.h_code[4 * i], d = p.h_code[4 * i + 1], a = p.h_code[4 * i + 2], b = p.h_code[4 * i + 3];
+        o << "    ";
+        if (slot[(size_t)i] >= 0) o << reg(d) << " = U[" << slot[(size_t)i] << "];";
+        else if (!emit_statement(o, op, d, a, b)) return false;
         o << "\n";
     }
     o << "}\n\n";
@@ -144,17 +208,28 @@ static bool build_source(const std::vector<KnpProgram>& progs, std::string& out,
     std::ostringstream src;
     src << "#define KNP_GAMMA_JIT 1\n#define KNP_MAX_AUX " << KNP_MAX_AUX << "\n"
         << "typedef int knp_i32_t;\n#define int32_t knp_i32_t\n"
-        << "struct DevParams { double dt, F, C_M, psi; double z[3], Di[3], De[3]; };\n"
+        << "struct DevParams { double dt, F, C_M, psi; double z[3], Di[3], De[3]; double dz2i[3], dz2e[3], rFz[3], cmFz[3], rF; };\n"
         << "struct FieldPtrs { const double* ki[3]; const double* ke[3]; const double* phim; const double* aux[KNP_MAX_AUX]; };\n"
+        << "#define KNP_JIT_UNIFORMS " << KNP_JIT_UNIFORMS << "\n"
         << "__device__ __forceinline__ double powi_d(double x, int e);\n\n";
+    int n_aux_used = 0;     // auxiliary nodal fields the programs read (highest slot + 1): the kernel interpolates exactly these
+    int xmask = 0;          // coordinate axes the programs read
     for (size_t i = 0; i < progs.size(); ++i) {
         if (progs[i].h_code.size() != (size_t)4 * progs[i].n_instr) { err = "program code not retained"; return false; }
+        for (int k = 0; k < progs[i].n_instr; ++k)
+            if (progs[i].h_code[4 * k] == KNP_OP_AUX) n_aux_used = std::max(n_aux_used, std::min(progs[i].h_code[4 * k + 2] + 1, (int)KNP_MAX_AUX));
+            else if (progs[i].h_code[4 * k] == KNP_OP_X) xmask |= 1 << (progs[i].h_code[4 * k + 2] & 3);
         if (!emit_program(src, (int)i, progs[i])) { err = "unknown opcode"; return false; }
     }
-    src << "__device__ __forceinline__ void knp_jit_eval(int prog, const double* __restrict__ C, const double* ki, const double* ke, double phim,\n"
-           "                                             const double* aux, const double* xq, double* I) {\n    switch (prog) {\n";
+    src << "#define KNP_JIT_NAUX " << n_aux_used << "\n#define KNP_JIT_XMASK " << xmask << "\n\n";
+    src << "__device__ __forceinline__ void knp_jit_pre(int prog, const double* __restrict__ C, double* U) {\n    switch (prog) {\n";
     for (size_t i = 0; i < progs.size(); ++i)
-        src << "        case " << i << ": knp_prog_" << i << "(C, ki, ke, phim, aux, xq, I); break;\n";
+        src << "        case " << i << ": knp_prog_" << i << "_pre(C, U); break;\n";
+    src << "        default: break;\n    }\n}\n\n";
+    src << "__device__ __forceinline__ void knp_jit_eval(int prog, const double* __restrict__ C, const double* U, const double* ki, const double* ke,\n"
+           "                                             double phim, const double* aux, const double* xq, double* I) {\n    switch (prog) {\n";
+    for (size_t i = 0; i < progs.size(); ++i)
+        src << "        case " << i << ": knp_prog_" << i << "(C, U, ki, ke, phim, aux, xq, I); break;\n";
     src << "        default: break;\n    }\n}\n\n" << kernel.str();
     out = src.str();
     return true;
@@ -189,6 +264,10 @@ static bool compile_source(const std::string& text, const std::string& arch_opt,
     code.resize(n);
     R.code(prog, code.data());
     R.destroy(&prog);
+    if (const char* dump = getenv("KNP_JIT_DUMP")) {      // developer aid: generated source + code object (llvm-objdump -d, readelf --notes)
+        std::ofstream(std::string(dump) + "/knp_gamma_jit.hip") << text;
+        std::ofstream(std::string(dump) + "/knp_gamma_jit.hsaco", std::ios::binary).write(code.data(), (std::streamsize)code.size());
+    }
     std::lock_guard<std::mutex> lock(cache_mutex());
     cache()[key] = code;
     return true;
@@ -247,7 +326,9 @@ void knp_jit_build(knp_ctx* ctx) {
         return;
     }
     hipFunction_t f3m = nullptr;
-    if (hipModuleGetFunction(&f3m, mod, "knp_gamma_vec_3d_many") != hipSuccess) { (void)hipGetLastError(); f3m = nullptr; }
+    const int qv = getenv("KNP_GAMMA_QV") ? atoi(getenv("KNP_GAMMA_QV")) : 1;     // points in flight per lane of the 4-lane kernel
+    const char* many_name = qv == 9 ? "knp_gamma_vec_3d_many" : "knp_gamma_vec_3d_q1";
+    if (hipModuleGetFunction(&f3m, mod, many_name) != hipSuccess) { (void)hipGetLastError(); f3m = nullptr; }
     ctx->jit_module = mod;
     ctx->jit_fn[0] = f2;
     ctx->jit_fn[1] = f3;

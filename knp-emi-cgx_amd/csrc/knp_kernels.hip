@@ -53,6 +53,11 @@ static constexpr int SIDE_SLOT = 120;  // 120..123: {norm, flag, phi sum, w.w} o
 struct DevParams {
     double dt, F, C_M, psi;
     double z[3], Di[3], De[3];
+    // derived on the host (make_params) so that they arrive as kernel arguments, i.e. in scalar registers: the facet kernels multiply by
+    // these at every quadrature point; computed per thread they would occupy 26 vector registers
+    double dz2i[3], dz2e[3];   // D_i^k z_k^2, D_e^k z_k^2
+    double rFz[3], cmFz[3];    // 1 / (F z_k), C_M / (F z_k)
+    double rF;                 // 1 / F
 };
 struct FieldPtrs {
     const double* ki[3];
@@ -543,8 +548,9 @@ k_gamma_pairs(int64_t n_gp, int n_g, int dim, DevParams P, const int32_t* __rest
         if (!PRECOND) {
             if (la > lb) { int t = la; la = lb; lb = t; }
             const int idx = la * dim - la * (la - 1) / 2 + (lb - la);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) m[k] += fmat[((size_t)k * npk + idx) * n_g + fct];
+            const double2* rec = reinterpret_cast<const double2*>(fmat + ((size_t)fct * npk + idx) * 6);   // 48-byte record of the facet's pair
+            const double2 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+            m[0] += r0.x; m[1] += r0.y; m[2] += r1.x; m[3] += r1.y; m[4] += r2.x; m[5] += r2.y;
         }
     }
     m0 *= P.C_M / P.F;
@@ -2329,7 +2335,14 @@ static void dev_free(T*& p) {
 static DevParams make_params(const knp_ctx* ctx) {
     DevParams P;
     P.dt = ctx->dt; P.F = ctx->F; P.C_M = ctx->C_M; P.psi = ctx->psi;
-    for (int j = 0; j < 3; ++j) { P.z[j] = ctx->z[j]; P.Di[j] = ctx->Di[j]; P.De[j] = ctx->De[j]; }
+    for (int j = 0; j < 3; ++j) {
+        P.z[j] = ctx->z[j]; P.Di[j] = ctx->Di[j]; P.De[j] = ctx->De[j];
+        P.dz2i[j] = P.Di[j] * P.z[j] * P.z[j];
+        P.dz2e[j] = P.De[j] * P.z[j] * P.z[j];
+        P.rFz[j] = 1.0 / (P.F * P.z[j]);
+        P.cmFz[j] = P.C_M * P.rFz[j];
+    }
+    P.rF = 1.0 / P.F;
     return P;
 }
 static FieldPtrs make_fields(const knp_fields* f) {
@@ -2988,11 +3001,13 @@ static int assemble_matrix_on_stream(knp_ctx* ctx, const knp_fields* fields, boo
                                ctx->d_fv, ctx->d_fmeas, ctx->d_qp, ctx->d_qw, f, 0, ctx->d_coords, ctx->d_gamma_prog,
                                (const int32_t* const*)nullptr, (const int32_t*)nullptr, (const double* const*)nullptr,
                                (const int32_t*)nullptr, 0, 0, ctx->d_fmat, ctx->d_fvec);
-        else if (gamma_many(g))   // 4 lanes x 9 points = the 36 points exactly (see gamma_many)
+        else if (gamma_many(g)) {  // 4 lanes per facet: the 36 points exactly (see gamma_many)
+            // (matrix part: 9 points in flight per lane 0.76 ms on 1.5 M facets, 3 points 0.82, 1 point 0.95 -- unlike the mechanism currents)
             hipLaunchKernelGGL((k_gamma_facets<3, true, false, 4, 9, 64, 1>), dim3((unsigned)(((int64_t)g.n_g * 4 + 63) / 64)), dim3(64), 0, ctx->stream, g.n_g, g.n_q, P,
                                ctx->d_fv, ctx->d_fmeas, ctx->d_qp, ctx->d_qw, f, 0, ctx->d_coords, ctx->d_gamma_prog,
                                (const int32_t* const*)nullptr, (const int32_t*)nullptr, (const double* const*)nullptr,
                                (const int32_t*)nullptr, 0, 0, ctx->d_fmat, ctx->d_fvec);
+        }
         else
             hipLaunchKernelGGL((k_gamma_facets<3, true, false, 16, 3, 64, 2>), dim3((unsigned)(((int64_t)g.n_g * 16 + 63) / 64)), dim3(64), 0, ctx->stream, g.n_g, g.n_q, P,
                                ctx->d_fv, ctx->d_fmeas, ctx->d_qp, ctx->d_qw, f, 0, ctx->d_coords, ctx->d_gamma_prog,
@@ -3423,15 +3438,16 @@ static int build_blocked(knp_ctx* ctx, int nf, int n_rows_scalar, int rs, int cs
     free_blocked(*out);
     if ((nf != 3 && nf != 4) || rs < nf || cs < nf || n_rows_scalar <= 0 || n_rows_scalar % rs != 0) return KNP_OK;
     const int nn = n_rows_scalar / rs;
+    // two passes over the node rows, both in parallel (the level-0 operators of a 10^7-unknown problem have ~10^8 entries: the
+    // single-threaded merge with push_back was most of the hierarchy upload): count + verify, prefix sum, fill
     std::vector<int32_t> brp((size_t)nn + 1, 0);
-    std::vector<float4> ev;
-    std::vector<int32_t> bci;
-    ev.reserve((size_t)rp[n_rows_scalar] / nf + 16);
-    if (nf == 4) bci.reserve((size_t)rp[n_rows_scalar] / nf + 16);
-    for (int i = 0; i < nn; ++i) {
+    std::vector<int32_t> cnt((size_t)nn, 0);
+    int bad = 0;
+    // merge of the nf sorted field rows of node row i by column node; emit(jmin, val) per union entry; false: structure violated
+    auto walk = [&](int i, auto&& emit) -> bool {
         const int r0 = rs * i;
         for (int k = nf; k < rs; ++k)
-            if (rp[r0 + k + 1] != rp[r0 + k]) return KNP_OK;
+            if (rp[r0 + k + 1] != rp[r0 + k]) return false;
         int64_t q[4], e[4];
         for (int k = 0; k < nf; ++k) { q[k] = rp[r0 + k]; e[k] = rp[r0 + k + 1]; }
         for (;;) {
@@ -3439,22 +3455,43 @@ static int build_blocked(knp_ctx* ctx, int nf, int n_rows_scalar, int rs, int cs
             for (int k = 0; k < nf; ++k)
                 if (q[k] < e[k]) {
                     const int c = ci[q[k]];
-                    if (c % cs != k) return KNP_OK;                                   // a field couples to another one
-                    if (q[k] > rp[r0 + k] && ci[q[k] - 1] >= c) return KNP_OK;        // row not sorted
+                    if (c % cs != k) return false;                                   // a field couples to another one
+                    if (q[k] > rp[r0 + k] && ci[q[k] - 1] >= c) return false;        // row not sorted
                     jmin = std::min(jmin, c / cs);
                 }
             if (jmin == INT32_MAX) break;
             float val[4] = {0.f, 0.f, 0.f, 0.f};
             for (int k = 0; k < nf; ++k)
                 if (q[k] < e[k] && ci[q[k]] / cs == jmin) val[k] = (float)v[q[k]++];
+            emit(jmin, val);
+        }
+        return true;
+    };
+#pragma omp parallel for schedule(static) reduction(+ : bad)
+    for (int i = 0; i < nn; ++i) {
+        int c = 0;
+        if (!walk(i, [&](int, const float*) { ++c; })) ++bad;
+        cnt[(size_t)i] = c;
+    }
+    if (bad) return KNP_OK;
+    int64_t total = 0;
+    for (int i = 0; i < nn; ++i) {
+        total += cnt[(size_t)i];
+        if (total > (int64_t)INT32_MAX) return KNP_OK;
+        brp[(size_t)i + 1] = (int32_t)total;
+    }
+    std::vector<float4> ev((size_t)total);
+    std::vector<int32_t> bci(nf == 4 ? (size_t)total : 0);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < nn; ++i) {
+        size_t o = (size_t)brp[(size_t)i];
+        (void)walk(i, [&](int jmin, const float* val) {
             float4 t;
             t.x = val[0]; t.y = val[1]; t.z = val[2];
-            if (nf == 4) { t.w = val[3]; bci.push_back(jmin); }
+            if (nf == 4) { t.w = val[3]; bci[o] = jmin; }
             else { const int32_t jj = jmin; float w; memcpy(&w, &jj, 4); t.w = w; }
-            ev.push_back(t);
-        }
-        if (ev.size() > (size_t)INT32_MAX) return KNP_OK;
-        brp[(size_t)i + 1] = (int32_t)ev.size();
+            ev[o++] = t;
+        });
     }
     const int64_t nnz = (int64_t)ev.size();
     if ((double)nnz * nf > 1.25 * (double)rp[n_rows_scalar] + 64.0) return KNP_OK;

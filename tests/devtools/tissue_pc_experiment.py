@@ -65,7 +65,7 @@ def variant(o, kind):
         state["A_id"] = A
         if kind in ("B", "D", "F"):
             state["Aphi"] = exact_block(A, pidx)
-        if kind in ("E", "G"):
+        if kind in ("E", "G", "I", "J", "H"):
             App = sp.csr_matrix((n, n))
             Asub = A[pidx][:, pidx].tocsr()
             # coupled potential block embedded at the potential unknowns
@@ -74,8 +74,13 @@ def variant(o, kind):
             h = amg.build_hierarchy(App, theta=0.08, coarse_size=2500)
             state["Vc"] = K.pc_amg_vcycle(h.levels, h.coarse_inv, PHI[0], PHI[1], PHI[2])
             state["rows"] = h.describe()["rows"]
-        if kind in ("C", "D"):
+        if kind in ("C", "D", "H"):
             state["Pk"] = exact_block(P, kidx)
+        if kind in ("I", "J"):     # exact ion solves on the intracellular (I) / extracellular (J) nodes only, V-cycle elsewhere
+            nodes = o.lay.node_i if kind == "I" else o.lay.node_e
+            nd = nodes[nodes >= 0]
+            sub = np.sort(np.concatenate([4 * nd + f for f in range(3)]))
+            state["Pk_part"] = (exact_block(P, sub), sub)
 
     def apply(r):
         setup_A()
@@ -85,7 +90,10 @@ def variant(o, kind):
             v = np.nonzero(nodes >= 0)[0]
             s[nodes[v]] = sum(p.z[j] ** 2 * o.k[side][j][v] for j in range(3))
         cc = p.psi / (s * ML)
-        z = state["Pk"](r) if kind in ("C", "D") else Vk(r)
+        z = state["Pk"](r) if kind in ("C", "D", "H") else Vk(r)
+        if kind in ("I", "J"):
+            ap_, sub = state["Pk_part"]
+            z[sub] = ap_(r)[sub]
         z[pidx] = 0.0
         zr = sum(zz[j] * r[j::4] for j in range(3))
         zk = sum(zz[j] * z[j::4] for j in range(3))
@@ -97,7 +105,7 @@ def variant(o, kind):
             w = state["Aphi"](t)
             z[pidx] = w[pidx]
             return z
-        elif kind == "E":
+        elif kind in ("E", "I", "J", "H"):
             w = state["Vc"](t)
         elif kind == "G":           # V-cycle on the coupled block, no Schur term
             w = state["Vc"](t)
@@ -112,7 +120,8 @@ def variant(o, kind):
 
 names = {"A": "btcc as built (V_k, V_phi on P_phiphi, cc)", "B": "V_k + EXACT coupled A_phiphi + cc", "C": "EXACT ions + V_phi(P) + cc",
          "D": "EXACT ions + EXACT coupled A_phiphi + cc", "E": "V_k + V-cycle on COUPLED A_phiphi + cc", "F": "V_k + EXACT coupled A_phiphi, no cc",
-         "G": "V_k + V-cycle on COUPLED A_phiphi, no cc"}
+         "G": "V_k + V-cycle on COUPLED A_phiphi, no cc", "I": "E with EXACT ion solves inside the cells", "J": "E with EXACT extracellular ion solves",
+         "H": "EXACT ions + V-cycle on COUPLED A_phiphi + cc"}
 for kind in (which or ["A", "B", "C", "D", "E", "F", "G"]):
     o = make()
     t0 = time.perf_counter()
