@@ -357,6 +357,7 @@ def main_case(args, world, rank, dist, torch):
             setattr(sp_, k, getattr(solver, k))
         sp_.fused = bool(be.stats()["fused"])
         sp_.coupled_phi = bool(getattr(solver, "_coupled_phi", False))
+        sp_.ion_dist, sp_.phi_dist = solver.ion_agg_distance(), solver.phi_agg_distance()
         info = {"case": {"kind": case["kind"], "N": case["N"], "pc": case["pc"]}, "solver": sp_, "snap": run["snap"]}
     return out, fail, info
 
@@ -515,12 +516,13 @@ def cpu_baseline(case, args, solver, snap):
         if not built:
             if pc == "btcc":
                 built["k"] = rnd(amg.build_hierarchy(amg.restrict_to_fields(P, (0, 1, 2)), theta=solver.amg_theta, coarse_size=solver.amg_coarse_size,
-                                                     node_fields=(4, (0, 1, 2)) if solver.amg_node_sync else None), coarse=fused)
+                                                     node_fields=(4, (0, 1, 2)) if solver.amg_node_sync else None, agg_distance=solver.ion_dist), coarse=fused)
                 built["p"] = rnd(amg.build_hierarchy(o.potential_block_of_A() if solver.coupled_phi else amg.restrict_to_fields(P, (3,)),
-                                                     theta=solver.amg_theta, coarse_size=solver.amg_coarse_size), level0_uploaded=solver.coupled_phi)
+                                                     theta=solver.amg_theta, coarse_size=solver.amg_coarse_size, agg_distance=solver.phi_dist),
+                                 level0_uploaded=solver.coupled_phi)
             else:
                 built["h"] = rnd(amg.build_hierarchy(P, theta=solver.amg_theta, coarse_size=solver.amg_coarse_size,
-                                                     node_fields=(4, (0, 1, 2, 3)) if solver.amg_node_sync else None))
+                                                     node_fields=(4, (0, 1, 2, 3)) if solver.amg_node_sync else None, agg_distance=solver.ion_dist))
         if pc == "btcc":
             return K.pc_btcc(o, wrap(built["k"]), wrap(built["p"]), pre, post, deg, fused=fused)
         h = wrap(built["h"])

@@ -40,12 +40,12 @@ class _Accel:
             from . import amg_gpu
             self.G = amg_gpu
 
-    def strength_and_aggregate(self, Aoo, theta, active_idx, seed):
+    def strength_and_aggregate(self, Aoo, theta, active_idx, seed, distance=2):
         """S (host csr pattern of the owned-owned block) and the aggregates of its active sub-graph"""
         if not self.gpu:
             S = amg.strength_graph(Aoo, theta)
             if active_idx.size:
-                agg, nagg = amg.aggregate(S[active_idx][:, active_idx].tocsr(), seed=seed)
+                agg, nagg = amg.aggregate(S[active_idx][:, active_idx].tocsr(), seed=seed, distance=distance)
             else:
                 agg, nagg = np.zeros(0, np.int64), 0
             return S, agg, nagg
@@ -59,7 +59,7 @@ class _Accel:
             return S, np.zeros(0, np.int64), 0
         n_act = int(active_idx.size)
         if n_act == n:
-            agg, nagg = G._aggregate(crow, col, n, seed, 2)
+            agg, nagg = G._aggregate(crow, col, n, seed, distance)
         else:
             active = torch.zeros(n, dtype=torch.bool, device=self.dev)
             active[torch.as_tensor(active_idx, device=self.dev)] = True
@@ -68,7 +68,7 @@ class _Accel:
             cc = skey - rr * n
             both = active[rr] & active[cc]
             crow_s, col_s = G._pattern_csr(newid[rr[both]] * n_act + newid[cc[both]], n_act)
-            agg, nagg = G._aggregate(crow_s, col_s, n_act, seed, 2)
+            agg, nagg = G._aggregate(crow_s, col_s, n_act, seed, distance)
         return S, agg.cpu().numpy(), int(nagg)
 
     def matmul(self, A, B):
@@ -174,7 +174,7 @@ def _exchange_ids(halo: LevelHalo, own_vals: np.ndarray) -> np.ndarray:
 
 
 def build_distributed_hierarchy(comm, P_loc: sp.csr_matrix, halo0: LevelHalo, own_gid_start0: int, ghost_gid0, ghost_owner0,
-                                theta=0.08, max_levels=12, coarse_size=2500, replicate_below=40000, device="cpu"):
+                                theta=0.08, max_levels=12, coarse_size=2500, replicate_below=40000, device="cpu", agg_distance=2):
     """P_loc: owned rows x [owned | ghost] columns of the level-0 operator.  Returns (levels, serial_tail) where
     ``levels`` are DistLevel objects (distributed part) and ``serial_tail`` is an ``amg.Hierarchy`` for the
     replicated coarse problem (identical on every rank)."""
@@ -206,7 +206,7 @@ def build_distributed_hierarchy(comm, P_loc: sp.csr_matrix, halo0: LevelHalo, ow
         # ---- aggregation on the owned-owned block (aggregates never cross ranks)
         active = diag != 0.0
         ia = np.nonzero(active)[0]
-        S, agg_a, nagg = X.strength_and_aggregate(Aoo, theta * 0.25 ** len(levels), ia, len(levels))
+        S, agg_a, nagg = X.strength_and_aggregate(Aoo, theta * 0.25 ** len(levels), ia, len(levels), amg._dist(agg_distance, len(levels)))
         counts = comm.all_gather_object(int(nagg))
         offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
         nagg_glob = int(offs[-1])
@@ -273,13 +273,15 @@ def build_distributed_hierarchy(comm, P_loc: sp.csr_matrix, halo0: LevelHalo, ow
             # the replicated tail is an ordinary serial hierarchy: built on the device like the single-GPU one (same algorithm and
             # priorities as the host version, which remains the fallback)
             tail = None
+            # the tail continues the per-level aggregation distances where the distributed levels stopped
+            tail_dist = [amg._dist(agg_distance, len(levels) + k) for k in range(max_levels)]
             if X.gpu:
                 try:
-                    tail = X.G.build_hierarchy(A_rep, theta=theta * 0.25 ** len(levels), coarse_size=coarse_size, device=X.dev)
+                    tail = X.G.build_hierarchy(A_rep, theta=theta * 0.25 ** len(levels), coarse_size=coarse_size, device=X.dev, agg_distance=tail_dist)
                 except (RuntimeError, NotImplementedError):
                     tail = None
             if tail is None:
-                tail = amg.build_hierarchy(A_rep, theta=theta * 0.25 ** len(levels), coarse_size=coarse_size)
+                tail = amg.build_hierarchy(A_rep, theta=theta * 0.25 ** len(levels), coarse_size=coarse_size, agg_distance=tail_dist)
             return levels, tail
         col_map = np.full(nagg_glob, -1, dtype=np.int64)
         col_map[offs[rank]:offs[rank + 1]] = np.arange(nagg)

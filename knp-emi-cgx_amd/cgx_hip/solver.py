@@ -85,7 +85,10 @@ class SolverKNPEMI:
     amg_fp32 = True        # mixed-precision preconditioner storage (operators fp32, vectors/Krylov fp64)
     amg_node_sync = True   # ion hierarchy: aggregate NODES once, all three ion fields share aggregates and sparsity patterns
     amg_split_decoupled = True   # unknowns without off-diagonal entries on a level are solved by its smoother, not coarsened further
-    amg_agg_distance = "2"  # aggregation distance per level of the first hierarchy (ions / all fields), last entry repeated: "2" | "1,2" | "1"
+    # aggregation distance per level (last entry repeated: "2" | "2,1" | "1") of the first hierarchy (ions / all fields) and of the
+    # potential hierarchy of btcc; "auto": see ion_agg_distance
+    amg_agg_distance = "auto"
+    amg_agg_distance_phi = "2"
     _b_is_final = False
     btcc_coupled_phi = True  # btcc on one GPU: potential hierarchy on the potential block of A (both sides + membrane coupling), not on P's
     amg_setup = "gpu"      # where the hierarchy is built: "gpu" (torch sparse products, cgx_hip/amg_gpu.py) | "host" (SciPy)
@@ -118,7 +121,7 @@ class SolverKNPEMI:
             if "gmres_restart" in ks: self.gmres_restart = int(ks["gmres_restart"])
             if "strict" in ks: self.strict = bool(ks["strict"])
             for k in ("amg_theta", "amg_cheby_degree", "amg_pre", "amg_post", "amg_coarse_size", "amg_replicate_below", "amg_fp32", "amg_setup", "amg_node_sync", "amg_split_decoupled",
-                      "btcc_coupled_phi", "amg_agg_distance"):
+                      "btcc_coupled_phi", "amg_agg_distance", "amg_agg_distance_phi"):
                 if k in ks: setattr(self, k, type(getattr(self, k))(ks[k]))
         if self.ksp_type != "gmres":
             raise NotImplementedError(f"ksp_type '{self.ksp_type}': only 'gmres' is implemented natively.")
@@ -196,7 +199,7 @@ class SolverKNPEMI:
             own_block = lambda M: M if M.shape[1] == be.n_dof_owned else M[:, :be.n_dof_owned].tocsr()
             P = own_block(P)                           # per-rank block (block-Jacobi across GPUs)
             # aggregation distance: the first hierarchy (the one built with node fields) may use smaller aggregates on its finest levels
-            dist_of = lambda nf: [int(v) for v in str(self.amg_agg_distance).replace(" ", "").split(",") if v] if nf is not None else 2
+            dist_of = lambda nf: self.ion_agg_distance() if nf is not None else self.phi_agg_distance()
             host_build = lambda M, nf=None: amg.build_hierarchy(M, theta=self.amg_theta, coarse_size=self.amg_coarse_size, node_fields=nf,
                                                                 split_decoupled=self.amg_split_decoupled, smoother_degree=self.amg_cheby_degree,
                                                                 agg_distance=dist_of(nf))
@@ -242,6 +245,24 @@ class SolverKNPEMI:
             self.print(f"AMG hierarchies: {[h.describe() for h in self.hierarchies]} (host setup {self.amg_setup_time:0.3f} s)")
         self.P_ = "device CSR (see Backend.precond_csr)"
 
+    def ion_agg_distance(self):
+        """Aggregation distance per level of the first hierarchy (``amg.build_hierarchy(agg_distance=...)``, last entry repeated).
+        ``auto``: distance 2 (a root and everything within two strong couplings) on the finest level, and in 3D distance 1 on every
+        level below it.  The Galerkin operators of smoothed aggregation on tetrahedral meshes have 40-100 entries per row from level 1 on:
+        distance-2 aggregates there swallow hundreds of fine nodes and the coarse correction degrades, while the level-0 aggregates keep
+        level 1 small (7-9 % of level 0), so the finer coarsening below costs little.  Measured on MI355X, btcc, ms per step (GMRES
+        iterations): cube 136^3 21.1 (9.5) -> 17.0 (6.7); cube 64^3 1.40 (4.75) -> 1.34 (4.26); tissue surrogate 97^3 with 13 824 cells
+        32.5 (19.9) -> 23.2 (13.8).  Distance 1 on all levels: 28.5 (12.6) on the tissue surrogate, 22.7 (5.8) / 3.07 (5.4) on the cubes (level 1
+        four times larger); "1,2": no gain.  In 2D (7-point graphs, coarse rows of 12-16 entries) distance 2 everywhere stays: 512^2 0.555 vs
+        0.561 ms with "2,1"."""
+        v = str(self.amg_agg_distance).replace(" ", "")
+        if v == "auto":
+            v = "2,1" if int(self.problem.mesh.geometry.dim) == 3 else "2"
+        return [int(t) for t in v.split(",") if t]
+
+    def phi_agg_distance(self):
+        return [int(t) for t in str(self.amg_agg_distance_phi).replace(" ", "").split(",") if t]
+
     def ion_node_fields(self):
         """``node_fields`` of the ion hierarchy (amg.build_hierarchy): the three ion blocks of P have the same graph"""
         return (4, (0, 1, 2)) if self.amg_node_sync else None
@@ -261,7 +282,8 @@ class SolverKNPEMI:
             Pm = P_loc if len(fields) == 4 else dist_amg.restrict_to_fields_rect(P_loc, fields)
             levels, tail = dist_amg.build_distributed_hierarchy(self.comm, Pm, halo0, start, ggid, gown, theta=self.amg_theta,
                                                                 coarse_size=self.amg_coarse_size,
-                                                                replicate_below=self.amg_replicate_below, device=be.device)
+                                                                replicate_below=self.amg_replicate_below, device=be.device,
+                                                                agg_distance=self.phi_agg_distance() if fields == (3,) else self.ion_agg_distance())
             dist_amg.upload(be.lib, be.ctx, be.check, levels, tail, self.amg_pre, self.amg_post, self.amg_cheby_degree, index=index)
             be.check(be.lib.knp_amg_use_native_level0(be.ctx, index, native_mode))
             for l, L in enumerate(levels):

@@ -2326,6 +2326,19 @@ static int dev_upload_raw(knp_ctx* ctx, T** dst, const T* src, size_t n) {
     if (n) HIPCHK(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
     return KNP_OK;
 }
+// host-side passes over whole operators of the AMG upload, in parallel (10^8 entries on the finest levels of a 10^7-unknown problem)
+static bool cols_in_range(const int32_t* ci, int64_t nnz, int64_t hi) {
+    int64_t bad = 0;
+#pragma omp parallel for schedule(static) reduction(+ : bad)
+    for (int64_t k = 0; k < nnz; ++k) bad += (ci[k] < 0 || ci[k] >= hi) ? 1 : 0;
+    return bad == 0;
+}
+static std::vector<float> to_float(const double* v, int64_t nnz) {
+    std::vector<float> out((size_t)std::max<int64_t>(nnz, 0));
+#pragma omp parallel for schedule(static)
+    for (int64_t k = 0; k < nnz; ++k) out[(size_t)k] = (float)v[k];
+    return out;
+}
 template <typename T>
 static void dev_free(T*& p) {
     if (p) (void)hipFree((void*)p);
@@ -3582,13 +3595,12 @@ int knp_amg_set_level(knp_ctx* ctx, int32_t hier, int32_t level, int32_t n_rows,
     KnpAmgLevel& L = H.lv[level];
     const int64_t nnzA = A_rp[n_rows];
     const int n_loc = std::max(n_cols_halo, n_rows);
-    for (int64_t k = 0; k < nnzA; ++k)
-        if (A_ci[k] < 0 || A_ci[k] >= n_loc) { ctx->err = "AMG level matrix column out of range"; return KNP_E_ARG; }
+    if (!cols_in_range(A_ci, nnzA, n_loc)) { ctx->err = "AMG level matrix column out of range"; return KNP_E_ARG; }
     L.n = n_rows; L.n_loc = n_loc; L.n_coarse = n_coarse; L.lambda_max = lambda_max; L.A_nnz = nnzA;
     KCHK(dev_upload_raw(ctx, &L.A_rp, A_rp, (size_t)n_rows + 1));
     KCHK(dev_upload_raw(ctx, &L.A_ci, A_ci, (size_t)nnzA));
     if (ctx->amg_fp32) {   // one copy only: fp32 when the preconditioner is stored in mixed precision
-        std::vector<float> tmp(A_v, A_v + nnzA);
+        std::vector<float> tmp = to_float(A_v, nnzA);
         KCHK(dev_upload(ctx, &L.A_vf, tmp));
     } else {
         KCHK(dev_upload_raw(ctx, &L.A_v, A_v, (size_t)nnzA));
@@ -3598,16 +3610,14 @@ int knp_amg_set_level(knp_ctx* ctx, int32_t hier, int32_t level, int32_t n_rows,
     if (n_coarse > 0) {
         if (!P_rp || !P_ci || !P_v || !R_rp || !R_ci || !R_v) { ctx->err = "AMG transfer operators missing"; return KNP_E_ARG; }
         const int64_t nnzP = P_rp[n_rows], nnzR = R_rp[n_coarse];
-        for (int64_t k = 0; k < nnzP; ++k)
-            if (P_ci[k] < 0 || P_ci[k] >= n_coarse) { ctx->err = "AMG prolongator column out of range"; return KNP_E_ARG; }
-        for (int64_t k = 0; k < nnzR; ++k)
-            if (R_ci[k] < 0 || R_ci[k] >= n_rows) { ctx->err = "AMG restrictor column out of range"; return KNP_E_ARG; }
+        if (!cols_in_range(P_ci, nnzP, n_coarse)) { ctx->err = "AMG prolongator column out of range"; return KNP_E_ARG; }
+        if (!cols_in_range(R_ci, nnzR, n_rows)) { ctx->err = "AMG restrictor column out of range"; return KNP_E_ARG; }
         KCHK(dev_upload_raw(ctx, &L.P_rp, P_rp, (size_t)n_rows + 1));
         KCHK(dev_upload_raw(ctx, &L.P_ci, P_ci, (size_t)nnzP));
         KCHK(dev_upload_raw(ctx, &L.R_rp, R_rp, (size_t)n_coarse + 1));
         KCHK(dev_upload_raw(ctx, &L.R_ci, R_ci, (size_t)nnzR));
         if (ctx->amg_fp32) {
-            std::vector<float> tp(P_v, P_v + nnzP), tr(R_v, R_v + nnzR);
+            std::vector<float> tp = to_float(P_v, nnzP), tr = to_float(R_v, nnzR);
             KCHK(dev_upload(ctx, &L.P_vf, tp));
             KCHK(dev_upload(ctx, &L.R_vf, tr));
         } else {
@@ -3641,14 +3651,13 @@ int knp_amg_set_level_prolongator(knp_ctx* ctx, int32_t hier, int32_t level, int
     KnpAmgLevel& L = ctx->hier[hier].lv[level];
     if (L.n_coarse <= 0 || !P_rp || !P_ci || !P_v || n_rows_P < L.n || n_rows_P > L.n_loc) { ctx->err = "prolongator rows must cover the owned entries and at most the local ones"; return KNP_E_ARG; }
     const int64_t nnzP = P_rp[n_rows_P];
-    for (int64_t k = 0; k < nnzP; ++k)
-        if (P_ci[k] < 0 || P_ci[k] >= L.n_coarse) { ctx->err = "AMG prolongator column out of range"; return KNP_E_ARG; }
+    if (!cols_in_range(P_ci, nnzP, L.n_coarse)) { ctx->err = "AMG prolongator column out of range"; return KNP_E_ARG; }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     dev_free(L.P_rp); dev_free(L.P_ci); dev_free(L.P_v); dev_free(L.P_vf);
     KCHK(dev_upload_raw(ctx, &L.P_rp, P_rp, (size_t)n_rows_P + 1));
     KCHK(dev_upload_raw(ctx, &L.P_ci, P_ci, (size_t)nnzP));
     if (ctx->amg_fp32) {
-        std::vector<float> tp(P_v, P_v + nnzP);
+        std::vector<float> tp = to_float(P_v, nnzP);
         KCHK(dev_upload(ctx, &L.P_vf, tp));
     } else {
         KCHK(dev_upload_raw(ctx, &L.P_v, P_v, (size_t)nnzP));
@@ -3665,14 +3674,13 @@ int knp_amg_set_level_smoothed(knp_ctx* ctx, int32_t hier, int32_t level, int32_
     KnpAmgLevel& L = ctx->hier[hier].lv[level];
     if (L.n_coarse <= 0 || !S_rp || !S_ci || !S_v || n_rows != L.n) { ctx->err = "S needs a level with a coarser level below it and one row per level row"; return KNP_E_ARG; }
     const int64_t nnzS = S_rp[n_rows];
-    for (int64_t k = 0; k < nnzS; ++k)
-        if (S_ci[k] < 0 || S_ci[k] >= L.n_coarse) { ctx->err = "S column out of range"; return KNP_E_ARG; }
+    if (!cols_in_range(S_ci, nnzS, L.n_coarse)) { ctx->err = "S column out of range"; return KNP_E_ARG; }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     dev_free(L.S_rp); dev_free(L.S_ci); dev_free(L.S_v); dev_free(L.S_vf);
     KCHK(dev_upload_raw(ctx, &L.S_rp, S_rp, (size_t)n_rows + 1));
     KCHK(dev_upload_raw(ctx, &L.S_ci, S_ci, (size_t)nnzS));
     if (ctx->amg_fp32) {
-        std::vector<float> t(S_v, S_v + nnzS);
+        std::vector<float> t = to_float(S_v, nnzS);
         KCHK(dev_upload(ctx, &L.S_vf, t));
     } else {
         KCHK(dev_upload_raw(ctx, &L.S_v, S_v, (size_t)nnzS));
@@ -3699,10 +3707,8 @@ int knp_amg_set_level_coarse_fused(knp_ctx* ctx, int32_t hier, int32_t level, in
         return KNP_E_ARG;
     }
     const int64_t nnzR = Rt_rp[Rt_rows], nnzU = U_rp[U_rows];
-    for (int64_t k = 0; k < nnzR; ++k)
-        if (Rt_ci[k] < 0 || Rt_ci[k] >= L.n) { ctx->err = "Rt column out of range"; return KNP_E_ARG; }
-    for (int64_t k = 0; k < nnzU; ++k)
-        if (U_ci[k] < 0 || U_ci[k] >= L.n + L.n_coarse) { ctx->err = "U column out of range"; return KNP_E_ARG; }
+    if (!cols_in_range(Rt_ci, nnzR, L.n)) { ctx->err = "Rt column out of range"; return KNP_E_ARG; }
+    if (!cols_in_range(U_ci, nnzU, L.n + L.n_coarse)) { ctx->err = "U column out of range"; return KNP_E_ARG; }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     dev_free(L.Rt_rp); dev_free(L.Rt_ci); dev_free(L.Rt_v); dev_free(L.Rt_vf); dev_free(L.U_rp); dev_free(L.U_ci); dev_free(L.U_v); dev_free(L.U_vf);
     KCHK(dev_upload_raw(ctx, &L.Rt_rp, Rt_rp, (size_t)Rt_rows + 1));
@@ -3710,7 +3716,7 @@ int knp_amg_set_level_coarse_fused(knp_ctx* ctx, int32_t hier, int32_t level, in
     KCHK(dev_upload_raw(ctx, &L.U_rp, U_rp, (size_t)U_rows + 1));
     KCHK(dev_upload_raw(ctx, &L.U_ci, U_ci, (size_t)nnzU));
     if (ctx->amg_fp32) {
-        std::vector<float> t(Rt_v, Rt_v + nnzR), u(U_v, U_v + nnzU);
+        std::vector<float> t = to_float(Rt_v, nnzR), u = to_float(U_v, nnzU);
         KCHK(dev_upload(ctx, &L.Rt_vf, t));
         KCHK(dev_upload(ctx, &L.U_vf, u));
     } else {

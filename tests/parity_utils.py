@@ -98,12 +98,14 @@ def oracle_gmres_same_algorithm(kind, N, steps, pc, rtol, solver, models="ci"):
     def fac(P):
         if pc == "btcc":
             hk = rnd(amg.build_hierarchy(amg.restrict_to_fields(P, (0, 1, 2)), theta=solver.amg_theta, coarse_size=solver.amg_coarse_size,
-                                         node_fields=solver.ion_node_fields()), coarse=fused)
+                                         node_fields=solver.ion_node_fields(), agg_distance=solver.ion_agg_distance()), coarse=fused)
             coupled = bool(getattr(solver, '_coupled_phi', False))      # potential hierarchy on the potential block of A (both sides, coupled)
             hp = rnd(amg.build_hierarchy(o.potential_block_of_A() if coupled else amg.restrict_to_fields(P, (3,)),
-                                         theta=solver.amg_theta, coarse_size=solver.amg_coarse_size), level0_uploaded=coupled)
+                                         theta=solver.amg_theta, coarse_size=solver.amg_coarse_size, agg_distance=solver.phi_agg_distance()),
+                     level0_uploaded=coupled)
             return K.pc_btcc(o, hk, hp, pre, post, deg, fused=fused)
-        h = rnd(amg.build_hierarchy(P, theta=solver.amg_theta, coarse_size=solver.amg_coarse_size, node_fields=solver.all_node_fields()))
+        h = rnd(amg.build_hierarchy(P, theta=solver.amg_theta, coarse_size=solver.amg_coarse_size, node_fields=solver.all_node_fields(),
+                                    agg_distance=solver.ion_agg_distance()))
         return K.pc_amg_vcycle(h.levels, h.coarse_inv, pre, post, deg, fused=fused)
     _, its = o.run(steps, solver="gmres", pc=fac, rtol=rtol)
     return o, its

@@ -161,9 +161,9 @@ def test_membrane_dominated_surrogate_at_scale():
 
     def fac(P):
         hk = amg.fp32_stored(amg.build_hierarchy(amg.restrict_to_fields(P, (0, 1, 2)), theta=s.amg_theta, coarse_size=s.amg_coarse_size,
-                                                 node_fields=s.ion_node_fields()), coarse=True)
+                                                 node_fields=s.ion_node_fields(), agg_distance=s.ion_agg_distance()), coarse=True)
         hp = amg.fp32_stored(amg.build_hierarchy(o.potential_block_of_A() if s._coupled_phi else amg.restrict_to_fields(P, (3,)), theta=s.amg_theta,
-                                                 coarse_size=s.amg_coarse_size), level0_uploaded=s._coupled_phi)
+                                                 coarse_size=s.amg_coarse_size, agg_distance=s.phi_agg_distance()), level0_uploaded=s._coupled_phi)
         return K.pc_btcc(o, hk, hp, s.amg_pre, s.amg_post, s.amg_cheby_degree, fused=True)
     _, its = o.run(2, solver="gmres", pc=fac, rtol=1e-9)
     assert its == list(s.iterations[:2]), (its, s.iterations)
@@ -184,6 +184,9 @@ def test_many_cells_split_off_the_hierarchy(monkeypatch):
     monkeypatch.setattr(amg, "DENSE_LIMIT", 500)
     cfg = tissue_config(3, 25, 6, steps=2, rtol=1e-9, pc="btcc", stimulus=True, width=1)
     cfg["solver"]["ksp_settings"]["amg_coarse_size"] = 150
+    # distance-2 aggregates collapse every cell into ONE aggregate per field on one level (the scenario of this test); the distance-1
+    # aggregates the solver picks by itself for such a mesh (SolverKNPEMI.ion_agg_distance) shed the cells over several levels
+    cfg["solver"]["ksp_settings"]["amg_agg_distance"] = "2"
     p = make_problem(cfg, "ci")
     s = SolverKNPEMI(p, solver_config=p.solver_config)
     s.solve()
@@ -203,9 +206,9 @@ def test_many_cells_split_off_the_hierarchy(monkeypatch):
 
     def fac(P):
         hko = amg.fp32_stored(amg.build_hierarchy(amg.restrict_to_fields(P, (0, 1, 2)), theta=s.amg_theta, coarse_size=s.amg_coarse_size,
-                                                  node_fields=s.ion_node_fields()), coarse=True)
+                                                  node_fields=s.ion_node_fields(), agg_distance=s.ion_agg_distance()), coarse=True)
         hpo = amg.fp32_stored(amg.build_hierarchy(o.potential_block_of_A() if s._coupled_phi else amg.restrict_to_fields(P, (3,)), theta=s.amg_theta,
-                                                  coarse_size=s.amg_coarse_size), level0_uploaded=s._coupled_phi)
+                                                  coarse_size=s.amg_coarse_size, agg_distance=s.phi_agg_distance()), level0_uploaded=s._coupled_phi)
         assert hko.describe()["rows"] == hk.describe()["rows"] and hpo.describe()["rows"] == hp.describe()["rows"]
         return K.pc_btcc(o, hko, hpo, s.amg_pre, s.amg_post, s.amg_cheby_degree, fused=True)
     _, its = o.run(2, solver="gmres", pc=fac, rtol=1e-9)

@@ -328,6 +328,52 @@ def test_device_amg_setup_reproduces_the_host_setup():
         assert np.abs(h0.coarse_inv - h1.coarse_inv).max() <= 1e-8 * np.abs(h0.coarse_inv).max()
 
 
+def test_distance_one_aggregation_host_and_device_builders_agree():
+    """``agg_distance`` per level (SolverKNPEMI.ion_agg_distance: "2,1" in 3D -- distance-2 aggregates on the finest level, distance 1
+    below): roots from an independent set of the strength graph itself give smaller aggregates and more levels; both builders produce
+    the same hierarchies, and the V(1,1) cycle converges faster per cycle than with distance 2 everywhere on the thin-sheet lattice."""
+    import numpy as np
+    import knpemi_oracle as K
+    from cgx_hip import amg, amg_gpu, mesh as M
+    name = "tissue3d_9_2_w1.xdmf"
+    coords, cells, tags, ft, _ = M.load_mesh(name, name, 1e-6)
+    intra = tuple(int(t) for t in np.unique(tags) if t != 1)
+    gam, gt, _ = M.gamma_integration_entities(cells, tags, intra, (1,), "intra")
+    o = K.OracleKNPEMI(coords / 1e-6, cells, tags, intra_tags=intra, extra_tag=1, gamma=gam, gamma_tag=gt, models=[K.Model("passive", intra)],
+                       mesh_conversion_factor=1e-6)
+    Pk = amg.restrict_to_fields(o.assemble_P(), (0, 1, 2))
+    kw = dict(theta=0.08, coarse_size=60, node_fields=(4, (0, 1, 2)))
+    h2 = amg.build_hierarchy(Pk, agg_distance=[2], **kw)
+    h1 = amg.build_hierarchy(Pk, agg_distance=[1], **kw)
+    g1 = amg_gpu.build_hierarchy(Pk, agg_distance=[1], device="cpu", **kw)
+    assert h1.describe()["rows"] == g1.describe()["rows"]
+    kw21 = dict(theta=0.08, coarse_size=30, node_fields=(4, (0, 1, 2)), agg_distance=[2, 1])
+    h21, g21 = amg.build_hierarchy(Pk, **kw21), amg_gpu.build_hierarchy(Pk, device="cpu", **kw21)
+    assert h21.describe()["rows"] == g21.describe()["rows"] and h21.levels[1].A.shape[0] == h2.levels[1].A.shape[0]
+    assert len(h1.levels) >= len(h2.levels) and h1.levels[1].A.shape[0] > h2.levels[1].A.shape[0]      # smaller aggregates
+    for a, b in zip(h1.levels, g1.levels):
+        assert abs(a.A - b.A).max() <= 1e-12 * abs(a.A).max()
+        if a.P is not None:
+            assert abs(a.P - b.P).max() <= 1e-12
+    # convergence factor of the stationary iteration e <- (I - V A) e on the ion block
+    n = Pk.shape[0]
+    ion = np.setdiff1d(np.arange(n), np.arange(3, n, 4))
+
+    def factor(h):
+        V = K.pc_amg_vcycle(h.levels, h.coarse_inv, 1, 1, 1)
+        e = np.zeros(n)
+        e[ion] = np.random.default_rng(0).standard_normal(ion.size)
+        r = 1.0
+        for _ in range(12):
+            e2 = e - V(Pk @ e)
+            e2[3::4] = 0.0
+            r = np.linalg.norm(e2) / np.linalg.norm(e)
+            e = e2 / np.linalg.norm(e2)
+        return r
+    f1, f2 = factor(h1), factor(h2)
+    assert f1 < f2 and f1 < 0.6, (f1, f2)
+
+
 def test_node_synchronised_aggregation_shares_patterns_between_fields():
     """``node_fields`` (amg.build_hierarchy): the ion fields are aggregated once, on the node graph of the first one, so
     coarse unknowns are numbered nf*aggregate+k and every operator of the hierarchy has the same sparsity pattern in all
