@@ -91,6 +91,10 @@ def aggregate(S: sp.csr_matrix, seed: int = 0, distance: int = 2) -> tuple[np.nd
     return agg, int(nagg)
 
 
+import os as _os
+_LAMBDA_PAD = float(_os.environ.get("KNP_AMG_LAMBDA_PAD", "1.05"))     # safety factor on the power-iteration estimate (developer knob)
+
+
 def estimate_lambda_max(A: sp.csr_matrix, dinv: np.ndarray, iters: int = 20, seed: int = 1) -> float:
     """Power iteration on D^{-1} A (largest magnitude eigenvalue), padded by 5 %."""
     rng = np.random.default_rng(seed)
@@ -103,7 +107,7 @@ def estimate_lambda_max(A: sp.csr_matrix, dinv: np.ndarray, iters: int = 20, see
         if lam == 0.0:
             return 1.0
         x = y / lam
-    return 1.05 * lam
+    return _LAMBDA_PAD * lam
 
 
 def _dist(agg_distance, level):
@@ -198,6 +202,8 @@ def _replicate_pattern(Sn: sp.csr_matrix, stride: int, fields, n_dof: int) -> sp
     return out
 
 
+import os as _os
+_THETA_DECAY = float(_os.environ.get("KNP_AMG_THETA_DECAY", "0.25"))   # strength threshold of level l = theta * decay^l (developer knob)
 DENSE_LIMIT = 6000      # largest coarsest level that gets a dense pseudo-inverse
 ELIMINATION_LEVEL_MAX = 200000   # levels up to this many coupled unknowns are searched for an independent set to eliminate exactly
 
@@ -361,7 +367,7 @@ def build_hierarchy(P: sp.csr_matrix, theta: float = 0.08, max_levels: int = 12,
             nf = len(fields)
             nn = n // stride
             A0 = A[fields[0]::stride][:, fields[0]::stride].tocsr()
-            Sn = strength_graph(A0, theta * 0.25 ** len(levels))
+            Sn = strength_graph(A0, theta * _THETA_DECAY ** len(levels))
             if not levels:
                 # the other fields must be able to follow the first one's aggregates: a node that has strong neighbours there
                 # but none in field f (a row of f dominated by its diagonal, e.g. the membrane mass of the potential in the
@@ -387,7 +393,7 @@ def build_hierarchy(P: sp.csr_matrix, theta: float = 0.08, max_levels: int = 12,
             agg = np.concatenate([nf * agg_n + k for k in range(nf)])
             nagg = nf * nagg_n
         else:
-            S = strength_graph(A, theta * 0.25 ** len(levels))
+            S = strength_graph(A, theta * _THETA_DECAY ** len(levels))
             if inject:
                 rows_t = np.nonzero(active)[0]
                 agg, nagg = np.arange(rows_t.size), int(rows_t.size)

@@ -20,6 +20,7 @@ import torch
 from . import amg
 
 warnings.filterwarnings("ignore", message="Sparse CSR tensor support is in beta state")
+_THETA_DECAY = amg._THETA_DECAY
 
 
 class _Csr:
@@ -42,9 +43,11 @@ class _Csr:
         return torch.sparse_csr_tensor(self.crow, self.col, self.val, size=self.shape)
 
     def scipy(self):
-        M = sp.csr_matrix((self.val.cpu().numpy(), self.col.cpu().numpy().astype(np.int32), self.crow.cpu().numpy().astype(np.int32)),
-                          shape=self.shape)
-        M.sort_indices()
+        # index conversion on the device (half the transfer, no single-threaded NumPy pass over 10^8 entries); every _Csr comes out of
+        # _from_coo / _from_scipy with sorted rows, so SciPy's own O(nnz) check is skipped as well
+        idx = torch.int32 if max(self.shape[1], self.nnz) < 2 ** 31 - 1 else torch.int64
+        M = sp.csr_matrix((self.val.cpu().numpy(), self.col.to(idx).cpu().numpy(), self.crow.to(idx).cpu().numpy()), shape=self.shape)
+        M.has_sorted_indices = True
         return M
 
     def diagonal(self):
@@ -111,7 +114,7 @@ def _lambda_max(A: _Csr, dinv, iters=20, seed=1):
         if lam == 0.0:
             return 1.0
         x = y / lam
-    return 1.05 * lam
+    return amg._LAMBDA_PAD * lam
 
 
 def _strength(A: _Csr, theta):
@@ -177,6 +180,31 @@ def _aggregate(crow, col, n, seed, distance):
     return agg, nagg
 
 
+class _Laps:
+    """KNP_AMG_TIMING=1: where the device-side setup spends its time (synchronising laps; developer aid)"""
+
+    def __init__(self, device):
+        import os
+        self.on = bool(os.environ.get("KNP_AMG_TIMING")) and str(device).startswith("cuda")
+        self.t, self.last = {}, 0.0
+        if self.on:
+            import time
+            torch.cuda.synchronize()
+            self.last = time.perf_counter()
+
+    def __call__(self, name):
+        if self.on:
+            import time
+            torch.cuda.synchronize()
+            now = time.perf_counter()
+            self.t[name] = self.t.get(name, 0.0) + now - self.last
+            self.last = now
+
+    def report(self, rows):
+        if self.on:
+            print("[amg_gpu] levels", rows, {k: round(v, 3) for k, v in self.t.items()}, flush=True)
+
+
 def build_hierarchy(P, theta: float = 0.08, max_levels: int = 12, coarse_size: int = 2500, agg_distance=2, device="cuda", node_fields=None,
                     split_decoupled: bool = True, smoother_degree: int = 1, eliminate_independent: bool = True):
     """Device version of ``amg.build_hierarchy`` (same arguments, same kind of result; ``node_fields``: aggregation on the node
@@ -184,9 +212,11 @@ def build_hierarchy(P, theta: float = 0.08, max_levels: int = 12, coarse_size: i
     smoother and not carried to coarser levels, only with a degree-1 smoother -- see amg.build_hierarchy)."""
     split_decoupled = bool(split_decoupled) and int(smoother_degree) == 1
     eliminate_independent = bool(eliminate_independent) and int(smoother_degree) == 1
+    lap = _Laps(device)
     A = _from_scipy(P, device)
     A_host = sp.csr_matrix(P, dtype=np.float64)
     A_host.sort_indices()
+    lap("level-0 upload")
     levels = []
     after_elimination = False
     sync = node_fields is not None and len(node_fields[1]) > 1
@@ -197,6 +227,7 @@ def build_hierarchy(P, theta: float = 0.08, max_levels: int = 12, coarse_size: i
         active = diag != 0
         dinv = torch.where(active, 1.0 / torch.where(active, diag, torch.ones_like(diag)), torch.zeros_like(diag))
         lam = _lambda_max(A, dinv)
+        lap("lambda_max")
         iso = torch.zeros(n, dtype=torch.bool, device=diag.device)
         if split_decoupled:
             r_a, c_a, v_a = A.rows(), A.col, A.val
@@ -230,7 +261,7 @@ def build_hierarchy(P, theta: float = 0.08, max_levels: int = 12, coarse_size: i
             dinv = torch.where(iso, dinv / amg.cheby_first_coefficient(lam), dinv)
             active = active & ~iso
         n_act = n_core
-        th = theta * 0.25 ** len(levels)
+        th = theta * _THETA_DECAY ** len(levels)
         if sync:
             # node graph of the first field -> aggregates of nodes -> the same aggregates and strength pattern for every field
             nf, nn, f0 = len(fields), n // stride, fields[0]
@@ -284,6 +315,7 @@ def build_hierarchy(P, theta: float = 0.08, max_levels: int = 12, coarse_size: i
                 sub = newid[rr[both]] * n_act + newid[cc[both]]
                 crow_s, col_s = _pattern_csr(sub, n_act)
                 agg, nagg = _aggregate(crow_s, col_s, n_act, len(levels), amg._dist(agg_distance, len(levels)))
+        lap("strength + aggregation")
         if nagg >= 0.9 * n_act and not inject:
             levels.append(amg.Level(A_host, dinv.cpu().numpy(), lam))
             break
@@ -314,13 +346,16 @@ def build_hierarchy(P, theta: float = 0.08, max_levels: int = 12, coarse_size: i
             rAFT = AFT.rows()
             Pm = _from_coo(torch.cat([T.rows(), rAFT]), torch.cat([T.col, AFT.col]),
                            torch.cat([T.val, -omega * dFinv[rAFT] * AFT.val]), (n, nagg), drop_zeros=True)
+        lap("prolongator")
         R = _transpose(Pm)
         AP = _spgemm(A, Pm)
         Ac = _spgemm(R, AP)
+        lap("Galerkin product")
         # S = (I - c2 Dinv A) Pm: prolongation + post-smoothing step of the fused cycle as one operator
         rAP = AP.rows()
         c2 = amg.cheby_first_coefficient(lam)
         S = _from_coo(torch.cat([Pm.rows(), rAP]), torch.cat([Pm.col, AP.col]), torch.cat([Pm.val, -c2 * dinv[rAP] * AP.val]), (n, nagg))
+        lap("S")
         Rt_h = U_h = None
         if levels:      # intermediate level: both legs of the fused cycle as plain products (amg.coarse_fused_operators)
             rA, cA, vA = A.rows(), A.col, A.val
@@ -331,9 +366,11 @@ def build_hierarchy(P, theta: float = 0.08, max_levels: int = 12, coarse_size: i
             U = _from_coo(torch.cat([rA, dg, S.rows()]), torch.cat([cA, dg, S.col + n]),
                           torch.cat([-(c2 * c2) * dinv[rA] * vA * dinv[cA], 2.0 * c2 * dinv, S.val]), (n, n + nagg))
             Rt_h, U_h = Rt.scipy(), U.scipy()
+        lap("Rt, U")
         levels.append(amg.Level(A_host, dinv.cpu().numpy(), lam, Pm.scipy(), R.scipy(), S.scipy(), Rt_h, U_h))
         A = Ac
         A_host = Ac.scipy()
+        lap("copies to the host")
         if sync:
             stride, fields = len(fields), tuple(range(len(fields)))
     # the dense pseudo-inverse stays on the host (LAPACK): the device eigen-solver is not accurate enough for the nearly
@@ -342,4 +379,6 @@ def build_hierarchy(P, theta: float = 0.08, max_levels: int = 12, coarse_size: i
     coarse_inv = amg.dense_pseudo_inverse(last) if last.shape[0] <= amg.DENSE_LIMIT else None
     h = amg.Hierarchy(levels, coarse_inv)
     h.node_fields = len(node_fields[1]) if sync else 0
+    lap("dense inverse")
+    lap.report([lv.A.shape[0] for lv in levels])
     return h
