@@ -202,7 +202,8 @@ class _Laps:
 
     def report(self, rows):
         if self.on:
-            print("[amg_gpu] levels", rows, {k: round(v, 3) for k, v in self.t.items()}, flush=True)
+            import sys
+            print("[amg_gpu] levels", rows, {k: round(v, 3) for k, v in self.t.items()}, file=sys.stderr, flush=True)
 
 
 def build_hierarchy(P, theta: float = 0.08, max_levels: int = 12, coarse_size: int = 2500, agg_distance=2, device="cuda", node_fields=None,

@@ -190,6 +190,22 @@ class SolverKNPEMI:
                 phases[name] = phases.get(name, 0.0) + now - last[0]
                 last[0] = now
             be.check(be.lib.knp_amg_set_precision(be.ctx, 1 if self.amg_fp32 else 0))
+            up_lib = be.lib
+            if os.environ.get("KNP_AMG_TIMING"):      # developer aid: time per entry point of the hierarchy hand-over
+                class _Timed:
+                    def __init__(self, lib):
+                        self.lib, self.t = lib, {}
+
+                    def __getattr__(self, name):
+                        f = getattr(self.lib, name)
+
+                        def w(*a):
+                            t0 = time.perf_counter()
+                            r = f(*a)
+                            self.t[name] = self.t.get(name, 0.0) + time.perf_counter() - t0
+                            return r
+                        return w
+                up_lib = _Timed(be.lib)
             P = be.precond_csr()
             lap("fetch_P_csr")
             if self.comm.size > 1 and os.environ.get("KNP_DIST_PC", "global") != "bj":
@@ -221,7 +237,7 @@ class SolverKNPEMI:
             if self._pc_kind == _lib.PC_AMG:
                 self.hierarchy = build(P, self.all_node_fields())
                 lap("build_hierarchy")
-                amg.upload(be.lib, be.ctx, be.check, self.hierarchy, self.amg_pre, self.amg_post, self.amg_cheby_degree, index=0, level0_native=True)
+                amg.upload(up_lib, be.ctx, be.check, self.hierarchy, self.amg_pre, self.amg_post, self.amg_cheby_degree, index=0, level0_native=True)
                 be.check(be.lib.knp_amg_use_native_level0(be.ctx, 0, 1))   # level 0 is the library's own P
                 lap("upload")
                 self.hierarchies = [self.hierarchy]
@@ -234,13 +250,16 @@ class SolverKNPEMI:
                 lap("potential_block")
                 hp = build(Pphi)
                 lap("build_potential_hierarchy")
-                amg.upload(be.lib, be.ctx, be.check, hk, self.amg_pre, self.amg_post, self.amg_cheby_degree, index=0, level0_native=True)
-                amg.upload(be.lib, be.ctx, be.check, hp, self.amg_pre, self.amg_post, self.amg_cheby_degree, index=1, level0_native=not self._coupled_phi)
+                amg.upload(up_lib, be.ctx, be.check, hk, self.amg_pre, self.amg_post, self.amg_cheby_degree, index=0, level0_native=True)
+                amg.upload(up_lib, be.ctx, be.check, hp, self.amg_pre, self.amg_post, self.amg_cheby_degree, index=1, level0_native=not self._coupled_phi)
                 be.check(be.lib.knp_amg_use_native_level0(be.ctx, 0, 2))   # ion fields of P
                 be.check(be.lib.knp_amg_use_native_level0(be.ctx, 1, 4 if self._coupled_phi else 3))   # potential: uploaded coupled block | P's
                 lap("upload")
                 self.hierarchies = [hk, hp]
                 self.hierarchy = hk
+            if up_lib is not be.lib:
+                import sys
+                print("[amg upload] inside the library:", {k: round(v, 3) for k, v in up_lib.t.items()}, file=sys.stderr, flush=True)
             self.amg_setup_time = time.perf_counter() - tic
             self.print(f"AMG hierarchies: {[h.describe() for h in self.hierarchies]} (host setup {self.amg_setup_time:0.3f} s)")
         self.P_ = "device CSR (see Backend.precond_csr)"

@@ -2329,13 +2329,34 @@ static int dev_upload_raw(knp_ctx* ctx, T** dst, const T* src, size_t n) {
 // host-side passes over whole operators of the AMG upload, in parallel (10^8 entries on the finest levels of a 10^7-unknown problem)
 static bool cols_in_range(const int32_t* ci, int64_t nnz, int64_t hi) {
     int64_t bad = 0;
-#pragma omp parallel for schedule(static) reduction(+ : bad)
+#pragma omp parallel for schedule(static) reduction(+ : bad) num_threads(knp_host_threads())
     for (int64_t k = 0; k < nnz; ++k) bad += (ci[k] < 0 || ci[k] >= hi) ? 1 : 0;
     return bad == 0;
 }
-static std::vector<float> to_float(const double* v, int64_t nnz) {
-    std::vector<float> out((size_t)std::max<int64_t>(nnz, 0));
-#pragma omp parallel for schedule(static)
+// Uninitialised host array: its pages are first touched by the parallel loop that fills it (a std::vector value-initialises -- and
+// page-faults -- serially, which on arrays of 10^8 entries cost more than the fill itself)
+template <typename T>
+struct HostBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    explicit HostBuf(size_t n_) : p(static_cast<T*>(std::malloc(std::max<size_t>(n_, 1) * sizeof(T)))), n(n_) {}
+    ~HostBuf() { std::free(p); }
+    HostBuf(const HostBuf&) = delete;
+    HostBuf& operator=(const HostBuf&) = delete;
+    HostBuf(HostBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    T& operator[](size_t i) { return p[i]; }
+    const T* data() const { return p; }
+    size_t size() const { return n; }
+};
+template <typename T>
+static int dev_upload(knp_ctx* ctx, T** dst, const HostBuf<T>& src) {
+    if (!src.p) { ctx->err = "out of host memory"; return KNP_E_STATE; }
+    return dev_upload_raw(ctx, dst, src.data(), src.size());
+}
+static HostBuf<float> to_float(const double* v, int64_t nnz) {
+    HostBuf<float> out((size_t)std::max<int64_t>(nnz, 0));
+    if (!out.p) return out;
+#pragma omp parallel for schedule(static) num_threads(knp_host_threads())
     for (int64_t k = 0; k < nnz; ++k) out[(size_t)k] = (float)v[k];
     return out;
 }
@@ -2464,7 +2485,7 @@ static int build_transposed_contribs(knp_ctx* ctx) {
     if (total >= (1LL << 47) || (double)total > 1.5 * (double)g.contrib_k.size() + 1024.0) return KNP_OK;
     std::vector<double> tk((size_t)std::max<int64_t>(total, 1), 0.0);
     std::vector<uint8_t> ts((size_t)std::max<int64_t>(total, 1), 0);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(knp_host_threads())
     for (int n = 0; n < no; ++n) {
         const int p0 = g.pair_ptr[n], p1 = g.pair_ptr[n + 1];
         const int64_t base = meta[n] & 0xffffffffffffLL;
@@ -2500,7 +2521,7 @@ static int build_fused_cell_means(knp_ctx* ctx, const knp_mesh_desc* mesh, int G
     if (dmax <= 0 || dmax > 255 || lds > 64 * 1024 || g.node_cell.empty()) return KNP_OK;
     std::vector<uint8_t> ncv((size_t)nv1 * g.node_cell.size());
     int bad = 0;
-#pragma omp parallel for schedule(static) reduction(+ : bad)
+#pragma omp parallel for schedule(static) reduction(+ : bad) num_threads(knp_host_threads())
     for (int n = 0; n < no; ++n) {
         const int32_t* pc = g.pair_col.data() + g.pair_ptr[n];
         const int deg = g.pair_ptr[n + 1] - g.pair_ptr[n];
@@ -3480,7 +3501,7 @@ static int build_blocked(knp_ctx* ctx, int nf, int n_rows_scalar, int rs, int cs
         }
         return true;
     };
-#pragma omp parallel for schedule(static) reduction(+ : bad)
+#pragma omp parallel for schedule(static) reduction(+ : bad) num_threads(knp_host_threads())
     for (int i = 0; i < nn; ++i) {
         int c = 0;
         if (!walk(i, [&](int, const float*) { ++c; })) ++bad;
@@ -3493,9 +3514,10 @@ static int build_blocked(knp_ctx* ctx, int nf, int n_rows_scalar, int rs, int cs
         if (total > (int64_t)INT32_MAX) return KNP_OK;
         brp[(size_t)i + 1] = (int32_t)total;
     }
-    std::vector<float4> ev((size_t)total);
-    std::vector<int32_t> bci(nf == 4 ? (size_t)total : 0);
-#pragma omp parallel for schedule(static)
+    HostBuf<float4> ev((size_t)total);
+    HostBuf<int32_t> bci(nf == 4 ? (size_t)total : 0);
+    if (!ev.p || !bci.p) { ctx->err = "out of host memory"; return KNP_E_STATE; }
+#pragma omp parallel for schedule(static) num_threads(knp_host_threads())
     for (int i = 0; i < nn; ++i) {
         size_t o = (size_t)brp[(size_t)i];
         (void)walk(i, [&](int jmin, const float* val) {
@@ -3600,7 +3622,7 @@ int knp_amg_set_level(knp_ctx* ctx, int32_t hier, int32_t level, int32_t n_rows,
     KCHK(dev_upload_raw(ctx, &L.A_rp, A_rp, (size_t)n_rows + 1));
     KCHK(dev_upload_raw(ctx, &L.A_ci, A_ci, (size_t)nnzA));
     if (ctx->amg_fp32) {   // one copy only: fp32 when the preconditioner is stored in mixed precision
-        std::vector<float> tmp = to_float(A_v, nnzA);
+        HostBuf<float> tmp = to_float(A_v, nnzA);
         KCHK(dev_upload(ctx, &L.A_vf, tmp));
     } else {
         KCHK(dev_upload_raw(ctx, &L.A_v, A_v, (size_t)nnzA));
@@ -3617,7 +3639,7 @@ int knp_amg_set_level(knp_ctx* ctx, int32_t hier, int32_t level, int32_t n_rows,
         KCHK(dev_upload_raw(ctx, &L.R_rp, R_rp, (size_t)n_coarse + 1));
         KCHK(dev_upload_raw(ctx, &L.R_ci, R_ci, (size_t)nnzR));
         if (ctx->amg_fp32) {
-            std::vector<float> tp = to_float(P_v, nnzP), tr = to_float(R_v, nnzR);
+            HostBuf<float> tp = to_float(P_v, nnzP), tr = to_float(R_v, nnzR);
             KCHK(dev_upload(ctx, &L.P_vf, tp));
             KCHK(dev_upload(ctx, &L.R_vf, tr));
         } else {
@@ -3657,7 +3679,7 @@ int knp_amg_set_level_prolongator(knp_ctx* ctx, int32_t hier, int32_t level, int
     KCHK(dev_upload_raw(ctx, &L.P_rp, P_rp, (size_t)n_rows_P + 1));
     KCHK(dev_upload_raw(ctx, &L.P_ci, P_ci, (size_t)nnzP));
     if (ctx->amg_fp32) {
-        std::vector<float> tp = to_float(P_v, nnzP);
+        HostBuf<float> tp = to_float(P_v, nnzP);
         KCHK(dev_upload(ctx, &L.P_vf, tp));
     } else {
         KCHK(dev_upload_raw(ctx, &L.P_v, P_v, (size_t)nnzP));
@@ -3680,7 +3702,7 @@ int knp_amg_set_level_smoothed(knp_ctx* ctx, int32_t hier, int32_t level, int32_
     KCHK(dev_upload_raw(ctx, &L.S_rp, S_rp, (size_t)n_rows + 1));
     KCHK(dev_upload_raw(ctx, &L.S_ci, S_ci, (size_t)nnzS));
     if (ctx->amg_fp32) {
-        std::vector<float> t = to_float(S_v, nnzS);
+        HostBuf<float> t = to_float(S_v, nnzS);
         KCHK(dev_upload(ctx, &L.S_vf, t));
     } else {
         KCHK(dev_upload_raw(ctx, &L.S_v, S_v, (size_t)nnzS));
@@ -3716,7 +3738,7 @@ int knp_amg_set_level_coarse_fused(knp_ctx* ctx, int32_t hier, int32_t level, in
     KCHK(dev_upload_raw(ctx, &L.U_rp, U_rp, (size_t)U_rows + 1));
     KCHK(dev_upload_raw(ctx, &L.U_ci, U_ci, (size_t)nnzU));
     if (ctx->amg_fp32) {
-        std::vector<float> t = to_float(Rt_v, nnzR), u = to_float(U_v, nnzU);
+        HostBuf<float> t = to_float(Rt_v, nnzR), u = to_float(U_v, nnzU);
         KCHK(dev_upload(ctx, &L.Rt_vf, t));
         KCHK(dev_upload(ctx, &L.U_vf, u));
     } else {

@@ -4,6 +4,9 @@
 // DofMapRestriction + create_matrix_block (reference: src/CGx/KNPEMI/KNPEMIx_problem.py:75-94,
 // src/CGx/KNPEMI/KNPEMIx_solver.py:157-161) -- but built so that assembly on the GPU is a
 // deterministic gather (no hashing, no atomics).
+#include <cstdlib>
+#include <cstdio>
+#include <sched.h>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -127,7 +130,7 @@ int knp_build_graph(const knp_mesh_desc* m, KnpHostGraph& g) {
     // ---- 3. pairs + contributions: count pass then fill pass -----------------------------
     std::vector<int32_t> npair(no + 1, 0);
     std::vector<int64_t> ncon(no + 1, 0);
-#pragma omp parallel
+#pragma omp parallel num_threads(knp_host_threads())
     {
         std::vector<int32_t> nbs;
 #pragma omp for schedule(dynamic, 4096)
@@ -162,7 +165,7 @@ int knp_build_graph(const knp_mesh_desc* m, KnpHostGraph& g) {
     for (size_t k = 0; k < nc.size(); ++k) g.node_cell[k] = nc[k] >> 2;
     const double mfac = 1.0 / ((dim + 1.0) * (dim + 2.0));
     bool degenerate = false;
-#pragma omp parallel
+#pragma omp parallel num_threads(knp_host_threads())
     {
         std::vector<Tup> tups;
 #pragma omp for schedule(dynamic, 4096)
@@ -342,7 +345,7 @@ int knp_build_csr_pattern(KnpHostGraph& g) {
     }
     g.rowptr[(size_t)4 * no] = (int32_t)nnz;
     g.colind.resize(nnz);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(knp_host_threads())
     for (int n = 0; n < no; ++n) {
         int p0 = g.pair_ptr[n], deg = g.pair_ptr[n + 1] - p0;
         int A = g.node_gv[n];
@@ -360,4 +363,29 @@ int knp_build_csr_pattern(KnpHostGraph& g) {
         for (int r = 0; r < x; ++r) ci[4 * deg + r] = 4 * cross[r] + 3;
     }
     return KNP_OK;
+}
+
+int knp_host_threads() {
+    static const int n = [] {
+        if (const char* e = getenv("KNP_HOST_THREADS")) { const int v = atoi(e); if (v > 0) return v; }
+        int cpus = 0;
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) cpus = CPU_COUNT(&set);
+        if (cpus <= 0) cpus = 1;
+        double quota = 0.0;      // cgroup v2: "<quota> <period>" or "max <period>"; v1: two files
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[64] = {0};
+            long long period = 0;
+            if (fscanf(f, "%63s %lld", q, &period) == 2 && period > 0 && strcmp(q, "max") != 0) quota = atof(q) / (double)period;
+            fclose(f);
+        } else {
+            long long q = -1, per = 0;
+            if (FILE* fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(fq, "%lld", &q) != 1) q = -1; fclose(fq); }
+            if (FILE* fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(fp, "%lld", &per) != 1) per = 0; fclose(fp); }
+            if (q > 0 && per > 0) quota = (double)q / (double)per;
+        }
+        if (quota >= 1.0) cpus = std::min(cpus, (int)(quota + 0.5));
+        return std::max(1, std::min(cpus, quota >= 1.0 ? 32 : 16));
+    }();
+    return n;
 }

@@ -574,11 +574,11 @@ def test_reassemble_P_rebuilds_the_preconditioner_every_step(pc):
 
     def spy():
         orig()
-        seen.append((id(s.hierarchy), s.backend.precond_csr().data.copy()))
+        seen.append((s.hierarchy, s.backend.precond_csr().data.copy()))    # the object itself: an id may be reused once it is collected
     s.assemble_preconditioner = spy
     s.solve()
     assert len(seen) == 4 and all(r > 0 for r in s.reasons)          # once before the loop + steps 2, 3, 4
-    assert len({h for h, _ in seen}) == 4                             # a new hierarchy every time
+    assert len({id(h) for h, _ in seen}) == 4                         # a new hierarchy every time
     assert np.abs(seen[-1][1] - seen[0][1]).max() > 0                 # P moved with the concentrations
     o = run_oracle(N=16, steps=4)
     gam = (o.lay.node_i >= 0) & (o.lay.node_e >= 0)
