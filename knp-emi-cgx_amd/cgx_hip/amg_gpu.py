@@ -64,8 +64,23 @@ class _Csr:
 def _from_scipy(M, device):
     M = sp.csr_matrix(M, dtype=np.float64)
     M.sort_indices()
-    return _Csr(torch.as_tensor(M.indptr.astype(np.int64), device=device), torch.as_tensor(M.indices.astype(np.int64), device=device),
+    # indices travel as they are (int32 for everything below 2^31 entries) and are widened on the device
+    return _Csr(torch.as_tensor(M.indptr, device=device).to(torch.int64), torch.as_tensor(M.indices, device=device).to(torch.int64),
                 torch.as_tensor(M.data, device=device), M.shape)
+
+
+def _restrict_fields(A: _Csr, fields, block: int = 4) -> _Csr:
+    """``amg.restrict_to_fields`` on the device: rows and columns of the other fields dropped (same size), explicit zeros dropped"""
+    dev = A.val.device
+    n = A.shape[0]
+    fmask = torch.zeros(block, dtype=torch.bool, device=dev)
+    fmask[list(fields)] = True
+    r = A.rows()
+    keep = fmask[r % block] & fmask[A.col % block] & (A.val != 0)
+    r = r[keep]
+    crow = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    crow[1:] = torch.cumsum(torch.bincount(r, minlength=n), 0)
+    return _Csr(crow, A.col[keep], A.val[keep], A.shape)
 
 
 def _from_coo(r, c, v, shape, drop_zeros=False):
@@ -207,16 +222,21 @@ class _Laps:
 
 
 def build_hierarchy(P, theta: float = 0.08, max_levels: int = 12, coarse_size: int = 2500, agg_distance=2, device="cuda", node_fields=None,
-                    split_decoupled: bool = True, smoother_degree: int = 1, eliminate_independent: bool = True):
-    """Device version of ``amg.build_hierarchy`` (same arguments, same kind of result; ``node_fields``: aggregation on the node
+                    split_decoupled: bool = True, smoother_degree: int = 1, eliminate_independent: bool = True, fields=None):
+    """Device version of ``amg.build_hierarchy`` (same arguments, same kind of result; ``fields``: P is the matrix of all fields and the
+    hierarchy is built on ``amg.restrict_to_fields(P, fields)``, restricted on the device; ``node_fields``: aggregation on the node
     graph of the first field, shared by all fields; ``split_decoupled``: unknowns without off-diagonal entries are solved by the
     smoother and not carried to coarser levels, only with a degree-1 smoother -- see amg.build_hierarchy)."""
     split_decoupled = bool(split_decoupled) and int(smoother_degree) == 1
     eliminate_independent = bool(eliminate_independent) and int(smoother_degree) == 1
     lap = _Laps(device)
     A = _from_scipy(P, device)
-    A_host = sp.csr_matrix(P, dtype=np.float64)
-    A_host.sort_indices()
+    if fields is not None:
+        A = _restrict_fields(A, fields)
+        A_host = A.scipy()
+    else:
+        A_host = sp.csr_matrix(P, dtype=np.float64)
+        A_host.sort_indices()
     lap("level-0 upload")
     levels = []
     after_elimination = False
@@ -277,7 +297,8 @@ def build_hierarchy(P, theta: float = 0.08, max_levels: int = 12, coarse_size: i
                     Af = _from_coo(torch.div(r_[mf], stride, rounding_mode="floor"), torch.div(c_[mf], stride, rounding_mode="floor"), v_[mf], (nn, nn))
                     degf = torch.bincount(torch.div(_strength(Af, th), nn, rounding_mode="floor"), minlength=nn)
                     if bool(((degf == 0) & (deg0 > 0)).any()) or bool(((diag[f::stride] <= 0) & (diag[f0::stride] > 0)).any()):
-                        return build_hierarchy(P, theta, max_levels, coarse_size, agg_distance, device, None, split_decoupled, smoother_degree, eliminate_independent)
+                        return build_hierarchy(P, theta, max_levels, coarse_size, agg_distance, device, None, split_decoupled, smoother_degree, eliminate_independent,
+                                               fields)
             act_n = active[f0::stride]
             ian = torch.nonzero(act_n).squeeze(1)
             n_act_n = int(ian.numel())

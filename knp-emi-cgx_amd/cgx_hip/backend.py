@@ -554,10 +554,17 @@ class Backend:
             M = sp.csr_matrix((va, ci, rp), shape=(no, self.n_nodes))
             M.sort_indices()
             return M
-        rows = np.repeat(4 * np.arange(no, dtype=np.int64) + 3, np.diff(rp))
-        M = sp.csr_matrix((va, (rows, 4 * ci.astype(np.int64) + 3)), shape=(self.n_dof_owned, self.n_dof_local))
-        M.eliminate_zeros()        # right-angled simplices: half of the same-side pairs of a structured mesh have no stiffness coupling
-        M.sort_indices()
+        # CSR arrays written directly (row 4 node + 3 = the node's row, every other row empty): no detour through a COO matrix and its sort.
+        # Explicit zeros are dropped -- right-angled simplices: half of the same-side pairs of a structured mesh have no stiffness coupling
+        keep = va != 0.0
+        node_of_entry = np.repeat(np.arange(no, dtype=np.int32), np.diff(rp))
+        cnt = np.bincount(node_of_entry[keep], minlength=no)
+        indptr = np.zeros(self.n_dof_owned + 1, dtype=np.int64)
+        indptr[4 * np.arange(no, dtype=np.int64) + 4] = cnt
+        np.cumsum(indptr, out=indptr)
+        idx_t = np.int32 if max(int(indptr[-1]), self.n_dof_local) < 2 ** 31 - 1 else np.int64
+        M = sp.csr_matrix((va[keep], (4 * ci[keep].astype(idx_t) + 3), indptr.astype(idx_t)), shape=(self.n_dof_owned, self.n_dof_local))
+        M.sort_indices()           # (a check only when the library's rows are already sorted)
         return M
 
     # ---- step timers (events in the library: one ctypes call per mark, one synchronisation per read) ------------------------

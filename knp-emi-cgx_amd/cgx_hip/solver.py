@@ -216,22 +216,24 @@ class SolverKNPEMI:
             P = own_block(P)                           # per-rank block (block-Jacobi across GPUs)
             # aggregation distance: the first hierarchy (the one built with node fields) may use smaller aggregates on its finest levels
             dist_of = lambda nf: self.ion_agg_distance() if nf is not None else self.phi_agg_distance()
-            host_build = lambda M, nf=None: amg.build_hierarchy(M, theta=self.amg_theta, coarse_size=self.amg_coarse_size, node_fields=nf,
-                                                                split_decoupled=self.amg_split_decoupled, smoother_degree=self.amg_cheby_degree,
-                                                                agg_distance=dist_of(nf))
+            # ``fields``: the hierarchy of a field class of P (ions (0, 1, 2), potential (3,)); the device builder restricts P itself
+            host_build = lambda M, nf=None, fields=None: amg.build_hierarchy(M if fields is None else amg.restrict_to_fields(M, fields), theta=self.amg_theta,
+                                                                             coarse_size=self.amg_coarse_size, node_fields=nf,
+                                                                             split_decoupled=self.amg_split_decoupled, smoother_degree=self.amg_cheby_degree,
+                                                                             agg_distance=dist_of(nf))
             if str(self.amg_setup) == "gpu":
                 from . import amg_gpu
 
-                def build(M, nf=None):
+                def build(M, nf=None, fields=None):
                     # the setup is host logic either way (the V-cycle always runs in the library): if torch's sparse
                     # products are not usable on this installation, build the same hierarchy with SciPy
                     try:
                         return amg_gpu.build_hierarchy(M, theta=self.amg_theta, coarse_size=self.amg_coarse_size, device=be.device, node_fields=nf,
                                                        split_decoupled=self.amg_split_decoupled, smoother_degree=self.amg_cheby_degree,
-                                                       agg_distance=dist_of(nf))
+                                                       agg_distance=dist_of(nf), fields=fields)
                     except (RuntimeError, NotImplementedError) as exc:
                         self.print(f"device-side AMG setup unavailable ({type(exc).__name__}: {exc}); using the host setup")
-                        return host_build(M, nf)
+                        return host_build(M, nf, fields)
             else:
                 build = host_build
             if self._pc_kind == _lib.PC_AMG:
@@ -242,13 +244,14 @@ class SolverKNPEMI:
                 lap("upload")
                 self.hierarchies = [self.hierarchy]
             else:
-                Pk = amg.restrict_to_fields(P, (0, 1, 2))
-                lap("restrict_ions")
-                hk = build(Pk, self.ion_node_fields())
+                hk = build(P, self.ion_node_fields(), (0, 1, 2))
                 lap("build_ion_hierarchy")
-                Pphi = own_block(be.precond_phi_csr()) if self._coupled_phi else amg.restrict_to_fields(P, (3,))
-                lap("potential_block")
-                hp = build(Pphi)
+                if self._coupled_phi:
+                    Pphi = own_block(be.precond_phi_csr())
+                    lap("potential_block")
+                    hp = build(Pphi)
+                else:
+                    hp = build(P, None, (3,))
                 lap("build_potential_hierarchy")
                 amg.upload(up_lib, be.ctx, be.check, hk, self.amg_pre, self.amg_post, self.amg_cheby_degree, index=0, level0_native=True)
                 amg.upload(up_lib, be.ctx, be.check, hp, self.amg_pre, self.amg_post, self.amg_cheby_degree, index=1, level0_native=not self._coupled_phi)
