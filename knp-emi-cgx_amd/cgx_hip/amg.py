@@ -439,13 +439,44 @@ def build_hierarchy(P: sp.csr_matrix, theta: float = 0.08, max_levels: int = 12,
     return h
 
 
+def cpu_share() -> int:
+    """CPUs this process may really use: the cgroup quota where there is one (a GPU box shows all logical CPUs of its host but grants a
+    job a fraction), else the affinity mask -- the Python-side twin of the library's ``knp_host_threads``"""
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        if q != "max" and float(per) > 0:
+            n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = int(f.read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, 32))
+
+
 def dense_pseudo_inverse(A: sp.spmatrix) -> np.ndarray:
     """Pseudo-inverse of the coarsest operator (the potential blocks are singular up to the membrane term).  The
     Galerkin operators of the symmetric blocks of P are symmetric: the eigenvalue route is 3-4x cheaper than the SVD,
     which used to be half of the whole host setup; operators with Dirichlet (identity) rows take the general route."""
     D = A.toarray()
     sym = np.abs(D - D.T).max() <= 1e-12 * max(np.abs(D).max(), 1e-300)
-    return np.linalg.pinv(D, rcond=1e-13, hermitian=bool(sym))
+    try:        # LAPACK on the CPU share of the process, not on every logical CPU of the host
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=cpu_share()):
+            return np.linalg.pinv(D, rcond=1e-13, hermitian=bool(sym))
+    except ImportError:
+        return np.linalg.pinv(D, rcond=1e-13, hermitian=bool(sym))
 
 
 def upload(lib, ctx, check, hier: Hierarchy, pre: int = 1, post: int = 1, cheby_degree: int = 2, index: int = 0, level0_native: bool = False):

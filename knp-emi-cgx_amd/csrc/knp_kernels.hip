@@ -2823,9 +2823,11 @@ int knp_get_precond_csr(const knp_ctx* cctx, int32_t* rp, int32_t* ci, double* v
     knp_ctx* ctx = const_cast<knp_ctx*>(cctx);
     if (!ctx || !rp || !ci || !vals) return KNP_E_ARG;
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    std::vector<double> pm((size_t)4 * ctx->n_pairs);
-    HIPCHK(hipMemcpy(pm.data(), ctx->d_p_vals, pm.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HostBuf<double> pm((size_t)4 * ctx->n_pairs);
+    if (!pm.p) { ctx->err = "out of host memory"; return KNP_E_STATE; }
+    HIPCHK(hipMemcpy(pm.p, ctx->d_p_vals, pm.size() * sizeof(double), hipMemcpyDeviceToHost));
     const KnpHostGraph& g = ctx->g;
+#pragma omp parallel for schedule(static) num_threads(knp_host_threads())
     for (int n = 0; n < g.n_nodes_owned; ++n) {
         const int p0 = g.pair_ptr[n], deg = g.pair_ptr[n + 1] - p0;
         for (int f = 0; f < 4; ++f) {

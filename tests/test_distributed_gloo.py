@@ -185,6 +185,15 @@ def _setup_worker(rank, size, port, q):
         sigs = comm.all_gather_object(sig)
         assert all(s == sigs[0] for s in sigs)
         assert desc["rows"][0] == n and len(desc["rows"]) >= 3
+        # per-level aggregation distance (SolverKNPEMI.ion_agg_distance: "2,1" in 3D): distance-1 aggregates below the finest level give
+        # larger coarse levels and at least as many of them; the schedule continues into the replicated tail, identical on every rank
+        lv21, tail21 = dist_amg.build_distributed_hierarchy(comm, Aloc, halo, lo, ghost, owner, coarse_size=20, replicate_below=60, device="cpu",
+                                                            agg_distance=[2, 1])
+        d21 = dist_amg.describe(lv21, tail21, comm)
+        assert d21["rows"][:2] == desc["rows"][:2] and len(d21["rows"]) >= len(desc["rows"]) and d21["rows"][2] > desc["rows"][2], (d21, desc)
+        sig21 = (d21["rows"], [round(float(abs(lv.A).sum()), 9) for lv in tail21.levels]) if tail21 is not None else (d21["rows"], [])
+        sigs21 = comm.all_gather_object(sig21)
+        assert all(s == sigs21[0] for s in sigs21)
         q.put((rank, "ok"))
         dist.barrier()
         dist.destroy_process_group()
