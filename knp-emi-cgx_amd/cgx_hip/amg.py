@@ -462,6 +462,12 @@ def cpu_share() -> int:
                 n = min(n, max(1, int(q / per + 0.5)))
         except (OSError, ValueError):
             pass
+    try:        # one process per GPU: the ranks of a node share that budget
+        k = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
+        if k > 1:
+            n = max(1, n // k)
+    except ValueError:
+        pass
     return max(1, min(n, 32))
 
 

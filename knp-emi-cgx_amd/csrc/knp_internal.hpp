@@ -360,6 +360,6 @@ struct knp_ctx {
 
 // Threads of the host-side OpenMP loops: the CPU share of the process, not the machine.  A GPU box shows all logical CPUs of its host
 // (256) but grants a job a fraction of them (16 per GPU): 256 threads on a 16-core share spend their time descheduled inside barriers --
-// the hierarchy hand-over took 5-11 s instead of 2.  KNP_HOST_THREADS=<n> overrides; else the cgroup CPU quota, else the affinity mask,
-// at most 32.
+// the hierarchy hand-over took 5-11 s instead of 1.  KNP_HOST_THREADS=<n> overrides; else the cgroup CPU quota, else the affinity mask,
+// divided by LOCAL_WORLD_SIZE (one process per GPU), at most 32.
 int knp_host_threads();

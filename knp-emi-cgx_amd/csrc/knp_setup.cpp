@@ -385,6 +385,8 @@ int knp_host_threads() {
             if (q > 0 && per > 0) quota = (double)q / (double)per;
         }
         if (quota >= 1.0) cpus = std::min(cpus, (int)(quota + 0.5));
+        // one process per GPU: the ranks of a node share that budget (torchrun / bench.py export LOCAL_WORLD_SIZE)
+        if (const char* lws = getenv("LOCAL_WORLD_SIZE")) { const int k = atoi(lws); if (k > 1) cpus = std::max(1, cpus / k); }
         return std::max(1, std::min(cpus, quota >= 1.0 ? 32 : 16));
     }();
     return n;

@@ -306,6 +306,52 @@ def test_membrane_programs_compile_to_native_code_for_gfx950():
     assert lib.knp_jit_compile_check(bad.ctypes.data_as(C.POINTER(C.c_int32)), 1, b"gfx950", log, 4096) != 0
 
 
+def test_generated_membrane_code_hoists_constant_only_subexpressions(tmp_path, monkeypatch):
+    """csrc/knp_jit.cpp: instructions of a membrane program whose operands trace back to its constant table only (psi / z_k,
+    exp(-t / a_syn): a division or an exponential each, identical at all 36 quadrature points of a facet) are emitted into a prologue
+    ``knp_prog_<id>_pre`` that runs once per thread; the per-point function reads their results from ``U``.  The number of auxiliary
+    fields and the coordinate axes a program reads become compile-time constants of the generated source.  (That both versions compute
+    the same currents is the GPU test test_runtime_compiled_membrane_programs_match_interpreter.)"""
+    import ctypes as C
+    import numpy as np
+    from cgx_hip import _lib
+    from cgx_hip.fem import OPS
+    lib = _lib.load()
+    monkeypatch.setenv("KNP_JIT_DUMP", str(tmp_path))
+    # r0 = C[0]; r1 = C[1]; r2 = r0 / r1 (constants only); r3 = exp(r2) (constants only); r4 = ki[0]; r5 = aux[1]; r4 = r4 * r3;
+    # r4 = r4 / r5 (per point); r6 = xq[1]; r4 = r4 + r6; I[0] += r4
+    code = np.array([[OPS["CONST"], 0, 0, 0], [OPS["CONST"], 1, 1, 0], [OPS["DIV"], 2, 0, 1], [OPS["EXP"], 3, 2, 0], [OPS["KI"], 4, 0, 0],
+                     [OPS["AUX"], 5, 1, 0], [OPS["MUL"], 4, 4, 3], [OPS["DIV"], 4, 4, 5], [OPS["X"], 6, 1, 0], [OPS["ADD"], 4, 4, 6],
+                     [OPS["OUT"], 0, 0, 4]], dtype=np.int32)
+    log = C.create_string_buffer(4096)
+    rc = lib.knp_jit_compile_check(code.ctypes.data_as(C.POINTER(C.c_int32)), code.shape[0], b"gfx950", log, 4096)
+    assert rc == 0, log.value.decode()
+    src = (tmp_path / "knp_gamma_jit.hip").read_text()
+    pre = src[src.index("void knp_prog_0_pre("):src.index("void knp_prog_0(")]
+    main = src[src.index("void knp_prog_0("):src.index("void knp_jit_pre(")]
+    assert "r2 = r0 / r1; U[0] = r2;" in pre and "r3 = exp(r2); U[1] = r3;" in pre
+    assert "exp(" not in main and "r0 / r1" not in main and "r3 = U[1];" in main and "r4 = r4 / r5;" in main
+    assert "#define KNP_JIT_NAUX 2" in src and "#define KNP_JIT_XMASK 2" in src
+    assert (tmp_path / "knp_gamma_jit.hsaco").stat().st_size > 1000
+
+
+def test_device_builder_restricts_the_fields_itself():
+    """``amg_gpu.build_hierarchy(P, fields=...)``: the hierarchy of a field class of P built from the unrestricted matrix (the restriction
+    runs on the device) is the one built from ``amg.restrict_to_fields(P, fields)``."""
+    import numpy as np
+    import knpemi_oracle as K
+    from cgx_hip import amg, amg_gpu
+    P = K.make_cube(6, models=K.CI_MODELS()).assemble_P()
+    for fields, nf in (((0, 1, 2), (4, (0, 1, 2))), ((3,), None)):
+        kw = dict(theta=0.08, coarse_size=60, device="cpu", node_fields=nf, agg_distance=[2, 1])
+        h0 = amg_gpu.build_hierarchy(amg.restrict_to_fields(P, fields), **kw)
+        h1 = amg_gpu.build_hierarchy(P, fields=fields, **kw)
+        assert h0.describe() == h1.describe() and len(h0.levels) >= 2
+        assert (h0.levels[0].A != h1.levels[0].A).nnz == 0
+        for a, b in zip(h0.levels, h1.levels):
+            assert abs(a.A - b.A).max() == 0.0 and np.array_equal(a.dinv, b.dinv)
+
+
 def test_device_amg_setup_reproduces_the_host_setup():
     """cgx_hip/amg_gpu.py (torch sparse products; run here on CPU tensors) builds the hierarchy of cgx_hip/amg.py: same
     aggregates and level sizes, operators equal to rounding."""
