@@ -37,6 +37,9 @@
  *     Nothing throws or exits across the ABI.  Non-convergence is a *reason code*, not an error.
  *   - a ctx is bound to the HIP device current at knp_create and to one stream (knp_set_stream);
  *     it is not thread-safe; one ctx per GPU.
+ *   - the one-off host-side passes (graph build in knp_create, hierarchy hand-over in knp_amg_set_level*) are OpenMP loops sized to
+ *     the CPU share of the process: cgroup quota or affinity mask, divided by LOCAL_WORLD_SIZE, at most 32; KNP_HOST_THREADS=<n>
+ *     overrides.  Nothing on the per-step path uses host threads.
  *   - "host" pointers are read/written by the CPU during the call; "device" pointers are HBM
  *     addresses owned by the caller (e.g. torch tensors) unless stated otherwise.
  *   - unknown numbering: node = (vertex, side); DoF = 4*node + f, f = 0..2 ions, f = 3 potential.

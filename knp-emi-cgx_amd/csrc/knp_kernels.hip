@@ -1321,6 +1321,17 @@ __device__ __forceinline__ void bload_x(const double* __restrict__ x, int j, dou
         const double2 a = *reinterpret_cast<const double2*>(p);
         const double2 b = *reinterpret_cast<const double2*>(p + 2);
         xv[0] = a.x; xv[1] = a.y; xv[2] = b.x; xv[3] = b.y;
+    } else if (NF == 3 && XS == 3) {
+        // three unknowns per node, 24-byte records: every other one starts 8 bytes off a 16-byte boundary -- one 16-byte load of the
+        // aligned pair and one 8-byte load of the remaining unknown, chosen by address arithmetic (no divergence), instead of three
+        // 8-byte gathers
+        const int odd = (int)((reinterpret_cast<uintptr_t>(p) >> 3) & 1);      // (from the address: sub-vectors need not start on 16 bytes)
+        const double2 pr = *reinterpret_cast<const double2*>(p + odd);
+        const double s1 = p[odd ? 0 : 2];
+        xv[0] = odd ? s1 : pr.x;
+        xv[1] = odd ? pr.x : pr.y;
+        xv[2] = odd ? pr.y : s1;
+        xv[3] = 0.0;
     } else {
         xv[0] = p[0]; xv[1] = p[1]; xv[2] = p[2];
         xv[3] = NF == 4 ? p[3] : 0.0;
