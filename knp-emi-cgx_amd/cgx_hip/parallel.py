@@ -254,6 +254,72 @@ def cut_component_modes(coords, cells, is_intra_cell, gamma, vertex_owner, l2g, 
             "areas": np.array([areas_all[int(c)] for c in cut]), "total_area": float(meas.sum())}
 
 
+def morton_keys(coords: np.ndarray) -> np.ndarray:
+    """Z-order (Morton) key of every point: its coordinates quantised to 21 bits (3D) / 31 bits (2D) per axis, bits interleaved"""
+    x = np.asarray(coords, dtype=np.float64)
+    dim = x.shape[1]
+    lo = x.min(axis=0) if len(x) else np.zeros(dim)
+    span = (x.max(axis=0) - lo) if len(x) else np.ones(dim)
+    span = float(max(span.max(), 1e-300))              # one scale for all axes: cells of the curve stay cubes
+    bits = 21 if dim == 3 else 31
+    q = np.minimum(((x - lo) / span * (2 ** bits - 1)).astype(np.uint64), np.uint64(2 ** bits - 1))
+
+    def spread3(v):
+        v = (v | (v << np.uint64(32))) & np.uint64(0x1f00000000ffff)
+        v = (v | (v << np.uint64(16))) & np.uint64(0x1f0000ff0000ff)
+        v = (v | (v << np.uint64(8))) & np.uint64(0x100f00f00f00f00f)
+        v = (v | (v << np.uint64(4))) & np.uint64(0x10c30c30c30c30c3)
+        return (v | (v << np.uint64(2))) & np.uint64(0x1249249249249249)
+
+    def spread2(v):
+        v = (v | (v << np.uint64(16))) & np.uint64(0x0000ffff0000ffff)
+        v = (v | (v << np.uint64(8))) & np.uint64(0x00ff00ff00ff00ff)
+        v = (v | (v << np.uint64(4))) & np.uint64(0x0f0f0f0f0f0f0f0f)
+        v = (v | (v << np.uint64(2))) & np.uint64(0x3333333333333333)
+        return (v | (v << np.uint64(1))) & np.uint64(0x5555555555555555)
+    sp_ = spread3 if dim == 3 else spread2
+    key = np.zeros(len(x), dtype=np.uint64)
+    for a in range(dim):
+        key |= sp_(q[:, a]) << np.uint64(a)
+    return key
+
+
+def reorder_local_mesh(lm: LocalMesh, order: str = "morton") -> LocalMesh:
+    """The same local mesh with its vertices, cells and membrane facets renumbered along a space-filling curve (owned entities stay in
+    front of the ghost ones, ``l2g`` follows): unknowns that are neighbours in space become neighbours in memory, so the gathers of the
+    SpMV, of the level-0 preconditioner kernels and of the assembly find more of their operands in a cache line that is already there.
+    The counterpart of the graph reordering DOLFINx applies to the meshes it reads (the reference inherits it)."""
+    if order in (None, "", "native", "none"):
+        return lm
+    if order != "morton":
+        raise ValueError(f"vertex order '{order}': native | morton")
+    nvo, nv = int(lm.n_vertices_owned), lm.coords.shape[0]
+    key = morton_keys(lm.coords)
+    perm = np.concatenate([np.argsort(key[:nvo], kind="stable"), nvo + np.argsort(key[nvo:], kind="stable")])     # new -> old
+    inv = np.empty(nv, dtype=np.int64)
+    inv[perm] = np.arange(nv)
+    cells = inv[lm.cells].astype(lm.cells.dtype)
+    nco, nc = int(lm.n_cells_owned), cells.shape[0]
+    ckey = morton_keys(lm.coords[lm.cells].mean(axis=1))
+    cperm = np.concatenate([np.argsort(ckey[:nco], kind="stable"), nco + np.argsort(ckey[nco:], kind="stable")])
+    cinv = np.empty(nc, dtype=np.int64)
+    cinv[cperm] = np.arange(nc)
+    gamma = lm.gamma.copy()
+    gtags = lm.gamma_tags
+    if len(gamma):
+        gamma[:, 0] = cinv[lm.gamma[:, 0]]
+        gamma[:, 2] = cinv[lm.gamma[:, 2]]
+        gorder = np.argsort(gamma[:, 0], kind="stable")
+        gamma, gtags = gamma[gorder], lm.gamma_tags[gorder]
+    defl = lm.defl
+    if defl is not None and "vertex_mode_i" in defl:
+        defl = dict(defl, vertex_mode_i=np.asarray(defl["vertex_mode_i"])[perm])
+    return LocalMesh(coords=lm.coords[perm], cells=cells[cperm], cell_tags=lm.cell_tags[cperm], n_vertices_owned=nvo, n_cells_owned=nco,
+                     gamma=gamma, gamma_tags=gtags, l2g=lm.l2g[perm], ghost_owner=lm.ghost_owner[perm[nvo:] - nvo] if len(lm.ghost_owner) else lm.ghost_owner,
+                     n_vertices_global=lm.n_vertices_global, n_cells_global=lm.n_cells_global,
+                     description=lm.description + " (vertices and cells in Morton order)", defl=defl)
+
+
 def stacked_cubes_local_mesh(N, size, rank, scale=1.0) -> LocalMesh:
     """Weak-scaling workload: ``size`` unit cubes stacked along z (each with the reference's inner
     cube [0.25,0.75]^3 as one intracellular cell, reference src/CGx/utils/misc.py:256-398), N^3 boxes

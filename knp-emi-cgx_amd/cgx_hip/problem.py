@@ -342,6 +342,12 @@ class MixedDimensionalProblem(ABC):
             lm = partition_mesh(coords, cells, cell_tags, gamma, gtags, self.comm.size, self.comm.rank, intra_tags=self.intra_tags,
                                 method=self.config.get("partition", "rcb" if generated else "kway") if hasattr(self, "config") else None)
             lm.description = desc
+        # optional renumbering along a space-filling curve (config key ``vertex_order`` / KNP_VERTEX_ORDER: native | morton)
+        order = os.environ.get("KNP_VERTEX_ORDER") or (self.config.get("vertex_order", "native") if hasattr(self, "config") else "native")
+        if order not in ("native", "none", ""):
+            from .parallel import reorder_local_mesh
+            lm = reorder_local_mesh(lm, order)
+            self.mesh_description = lm.description
         self.local_mesh = lm
         self.mesh = meshmod.Mesh(lm.coords, lm.cells)
         self.mesh.comm = self.comm
