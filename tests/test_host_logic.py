@@ -783,3 +783,38 @@ def test_multilevel_kway_partition_beats_coordinate_bisection():
         lm = partition_mesh(X, T, tg, g, gt, 4, r, intra_tags=(2,), method="kway")
         seen[lm.l2g[:lm.n_vertices_owned]] += 1
     assert (seen == 1).all()
+
+
+def test_morton_reordering_keeps_the_mesh():
+    """cgx_hip/parallel.py reorder_local_mesh: the renumbered local mesh is the same mesh -- same cells as sets of global vertices, same
+    coordinates per global vertex, same membrane facets with matching local facet indices on both sides, tags carried along, owned
+    entities still in front -- and the Morton keys really follow a Z curve (a 2x2x2 block of lattice points is contiguous)."""
+    import numpy as np
+    from cgx_hip.parallel import morton_keys, reorder_local_mesh, stacked_cubes_local_mesh
+    lm = stacked_cubes_local_mesh(8, 1, 0, scale=1e-6)
+    m2 = reorder_local_mesh(lm, "morton")
+    assert reorder_local_mesh(lm, "native") is lm
+    assert m2.n_vertices_owned == lm.n_vertices_owned and m2.n_cells_owned == lm.n_cells_owned
+    assert np.array_equal(np.sort(m2.l2g), np.sort(lm.l2g)) and not np.array_equal(m2.l2g, lm.l2g)
+    assert np.allclose(lm.coords[np.argsort(lm.l2g)], m2.coords[np.argsort(m2.l2g)])
+
+    def cell_table(m):
+        return {tuple(sorted(m.l2g[c])): int(t) for c, t in zip(m.cells, m.cell_tags)}
+    assert cell_table(lm) == cell_table(m2)
+
+    def facets(m):
+        out = {}
+        for (cp, lfp, cm, lfm), t in zip(m.gamma, m.gamma_tags):
+            vp = sorted(m.l2g[v] for i, v in enumerate(m.cells[cp]) if i != lfp)
+            vm = sorted(m.l2g[v] for i, v in enumerate(m.cells[cm]) if i != lfm)
+            assert vp == vm
+            out[tuple(vp)] = (int(t), int(m.cell_tags[cp]), int(m.cell_tags[cm]))
+        return out
+    assert facets(lm) == facets(m2) and len(lm.gamma) > 0
+    g = np.array([[i, j, k] for k in range(4) for j in range(4) for i in range(4)], dtype=float)
+    order = np.argsort(morton_keys(g), kind="stable")
+    first8 = {tuple(g[i].astype(int)) for i in order[:8]}
+    assert first8 == {(i, j, k) for i in (0, 1) for j in (0, 1) for k in (0, 1)}
+    with __import__("pytest").raises(ValueError):
+        reorder_local_mesh(lm, "hilbert")
+
