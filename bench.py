@@ -326,6 +326,7 @@ def main_case(args, world, rank, dist, torch):
         "config": {"workload": f"{case['what']}, 3 ions, {'HH+ATP+cotransporters' if args.models == 'ci' else 'passive membrane'}, "
                                f"GMRES(30)+{'AMG on block-diagonal P' if case['pc'] in ('hypre', 'amg') else case['pc']}, rtol {args.rtol:g}",
                    "n_dof": int(n_dof), "nnz": int(be.nnz_global), "mechanisms": args.models, "pc": case["pc"],
+                   "amg_agg_distance": solver.ion_agg_distance(), "vertex_order": os.environ.get("KNP_VERTEX_ORDER", "native"),
                    "parallelism": f"dd{world}", "gmres_its_per_step": float(sum(run["its"])) / max(n_steps_timed, 1),
                    "converged_all": bool(all(r > 0 for r in run["reasons"])),
                    "phi_norms": [norms[0], norms[1]],
