@@ -817,4 +817,16 @@ def test_morton_reordering_keeps_the_mesh():
     assert first8 == {(i, j, k) for i in (0, 1) for j in (0, 1) for k in (0, 1)}
     with __import__("pytest").raises(ValueError):
         reorder_local_mesh(lm, "hilbert")
+    # partitioned meshes: ghosts stay behind the owned vertices and keep their owners
+    from cgx_hip import mesh as M
+    from cgx_hip.parallel import partition_mesh
+    coords, cells, tags, _, _ = M.load_mesh("cube6.xdmf", "cube6.xdmf", 1e-6)
+    intra = tuple(int(t) for t in np.unique(tags) if t != 1)
+    gam, gt, _ = M.gamma_integration_entities(cells, tags, intra, (1,), "intra")
+    parts = [reorder_local_mesh(partition_mesh(coords, cells, tags, gam, gt, 3, r, intra_tags=intra), "morton") for r in range(3)]
+    owned = [set(p.l2g[:p.n_vertices_owned].tolist()) for p in parts]
+    assert sum(len(o) for o in owned) == coords.shape[0]
+    for p in parts:
+        assert len(set(p.l2g.tolist())) == len(p.l2g)
+        assert all(int(g) in owned[int(o)] for g, o in zip(p.l2g[p.n_vertices_owned:], p.ghost_owner))
 
