@@ -387,12 +387,15 @@ class MixedDimensionalProblem(ABC):
         if isinstance(integrand, (int, float)):
             val = float(integrand) * float(self._fmeas[sel].sum())
         else:
-            X = self.mesh.geometry.x[fv]                                  # (n, d, dim)
-            xq = np.einsum("qa,nad->nqd", self.q_pts, X)
-            env = {"x": [xq[:, :, k] for k in range(xq.shape[2])], "fields": {}}
-            vals = fem.evaluate_numpy(integrand, env)
-            vals = np.broadcast_to(vals, xq.shape[:2])
-            val = float((self._fmeas[sel][:, None] * vals * self.q_w[None, :]).sum())
+            # in blocks of facets (10^7 facets x 36 quadrature points x 3 coordinates would be 10 GB at once); the quadrature points as one
+            # batched matrix product
+            val, fm, x = 0.0, self._fmeas[sel], self.mesh.geometry.x
+            for lo in range(0, fv.shape[0], 1 << 19):
+                X = x[fv[lo:lo + (1 << 19)]]                                  # (n, d, dim)
+                xq = np.matmul(self.q_pts[None, :, :], X)                     # (n, q, dim)
+                env = {"x": [xq[:, :, k] for k in range(xq.shape[2])], "fields": {}}
+                vals = np.broadcast_to(fem.evaluate_numpy(integrand, env), xq.shape[:2])
+                val += float((fm[lo:lo + (1 << 19)][:, None] * vals * self.q_w[None, :]).sum())
         return self.comm.allreduce_sum(val)
 
     # ---------------------------------------------------------------- backend plumbing
@@ -657,23 +660,36 @@ class ProblemKNPEMI(MixedDimensionalProblem):
             ion["E"] = (psi / ion["z"]) * fem.ln(ue_p[idx] / ui_p[idx])                # :516
             ion["I_ch"] = dict.fromkeys(self.gamma_tags, fem.ZeroBaseForm(None))
         I_ch = dict.fromkeys(self.gamma_tags, fem.ZeroBaseForm(None))
+        # The loop is the reference's (KNPEMIx_problem.py:504-555), tag by tag.  A tissue configuration carries one membrane tag per cell
+        # (10^5 of them at the size of configs[3]) with the same mechanisms on every one: a mechanism's expression for an ion -- and its
+        # stimulus term -- is built once and shared by its tags (expressions are immutable trees), and ``terms`` records which shared
+        # terms a tag's current consists of, so that tags with the same terms are compiled once further down.
+        stim_tags = set(self.stimulus_tags)
+        terms = {tag: [[] for _ in range(self.N_ions)] for tag in self.gamma_tags}
         for idx, ion in enumerate(self.ion_list):
             for model in self.ionic_models:
+                base = with_stim = stim = None
+                hh_na = ion["name"] == "Na" and isinstance(model, HodgkinHuxley)
                 for gamma_tag in model.tags:
-                    I_ch_k_ = model._eval(idx)
-                    if (gamma_tag in self.stimulus_tags and ion["name"] == "Na" and isinstance(model, HodgkinHuxley)):
-                        if self.stimulus_region:
-                            if not self.multiple_stimulus_directions:
-                                stim = model._add_stimulus(idx, step=True, range=self.stimulus_region_range, dir=self.stimulus_region_direction)
+                    if base is None:
+                        base = model._eval(idx)
+                    I_ch_k_ = base
+                    if hh_na and gamma_tag in stim_tags:
+                        if with_stim is None:
+                            if self.stimulus_region:
+                                if not self.multiple_stimulus_directions:
+                                    stim = model._add_stimulus(idx, step=True, range=self.stimulus_region_range, dir=self.stimulus_region_direction)
+                                else:
+                                    stim = model._add_stimulus(idx, step=True, range=self.stimulus_region_range, dir=self.stimulus_region_directions)
                             else:
-                                stim = model._add_stimulus(idx, step=True, range=self.stimulus_region_range, dir=self.stimulus_region_directions)
-                        else:
-                            stim = model._add_stimulus(idx, step=True)
-                        I_ch_k_ = I_ch_k_ + stim
+                                stim = model._add_stimulus(idx, step=True)
+                            with_stim = base + stim
+                        I_ch_k_ = with_stim
                         self.print(f"Stimulus added on membrane with tag {gamma_tag}.")
                         self.stim_ufl_expr = stim
                     ion["I_ch"][gamma_tag] = ion["I_ch"][gamma_tag] + I_ch_k_
                     I_ch[gamma_tag] = I_ch[gamma_tag] + I_ch_k_
+                    terms[gamma_tag][idx].append(id(I_ch_k_))
         # one bytecode program per membrane tag
         roles = {}
         for j in range(self.N_ions):
@@ -693,14 +709,19 @@ class ProblemKNPEMI(MixedDimensionalProblem):
         self.programs = {}
         self.tag_program = {}
         seen = {}
+        by_terms = {}      # tags whose currents are sums of the same shared terms: compiled once
         for k, tag in enumerate(self.gamma_tags):
+            tkey = tuple(tuple(t) for t in terms[tag])
+            if tkey in by_terms:
+                self.tag_program[k] = by_terms[tkey]
+                continue
             outs = [self.ion_list[j]["I_ch"][tag] for j in range(self.N_ions)]
             spec = fem.compile_program(outs, roles, self.aux_functions)
             key = (spec.code.tobytes(), tuple(ckey(c) for c in spec.const_sources))
             if key not in seen:
                 seen[key] = len(self.programs)
                 self.programs[seen[key]] = spec
-            self.tag_program[k] = seen[key]
+            self.tag_program[k] = by_terms[tkey] = seen[key]
         if self.backend is not None and getattr(self.backend, "tag_program", None) != self.tag_program:
             raise RuntimeError("setup_variational_form() changed the membrane-tag -> program map after the backend was created")
         self.a = "hard-wired in knp_kernels.hip (k_assemble_pairs, k_gamma_facets, k_gamma_pairs)"
