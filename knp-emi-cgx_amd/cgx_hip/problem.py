@@ -689,7 +689,7 @@ class ProblemKNPEMI(MixedDimensionalProblem):
                         self.stim_ufl_expr = stim
                     ion["I_ch"][gamma_tag] = ion["I_ch"][gamma_tag] + I_ch_k_
                     I_ch[gamma_tag] = I_ch[gamma_tag] + I_ch_k_
-                    terms[gamma_tag][idx].append(id(I_ch_k_))
+                    terms.setdefault(gamma_tag, [[] for _ in range(self.N_ions)])[idx].append(id(I_ch_k_))
         # one bytecode program per membrane tag
         roles = {}
         for j in range(self.N_ions):
