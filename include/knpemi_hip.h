@@ -217,6 +217,9 @@ const char* knp_jit_status(knp_ctx* ctx);
 /* test hook, needs neither a device nor a context: generate the HIP source for one program and compile it with hiprtc
  * for `arch` (e.g. "gfx950"); 0 on success, `log` receives the compiler log or a one-line summary */
 int knp_jit_compile_check(const int32_t* code, int32_t n_instr, const char* arch, char* log, int32_t log_cap);
+/* test hook, needs neither a device nor a context: the number of host threads the one-off OpenMP passes of the library use in this
+ * process (KNP_HOST_THREADS, else cgroup CPU quota / affinity mask divided by LOCAL_WORLD_SIZE, at most 32; evaluated once) */
+int knp_host_thread_count(void);
 int knp_set_program_constants(knp_ctx* ctx, int32_t prog_id, int32_t n_consts, const double* consts);
 /* Dirichlet conditions (reference: dfx.fem.dirichletbc + bcs= of assemble_*_block, KNPEMIx_problem.py:106-134,
  * KNPEMIx_solver.py:114-116): rows of the listed owned DoFs become identity rows in A and P at every assembly;

@@ -100,6 +100,7 @@ SIGNATURES = {
     "knp_jit_status": (C.c_char_p, [vp]),
     "knp_gmres_prepare": (C.c_int, [vp, vp]),
     "knp_jit_compile_check": (C.c_int, [C.POINTER(C.c_int32), C.c_int32, C.c_char_p, C.c_char_p, C.c_int32]),
+    "knp_host_thread_count": (C.c_int, []),
     "knp_p2p_init": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_double]),
     "knp_p2p_shutdown": (C.c_int, [vp]),
     "knp_p2p_plan_create": (C.c_int, [vp, C.c_int32, C.c_int64, C.c_int64, C.POINTER(C.c_int32), vp]),

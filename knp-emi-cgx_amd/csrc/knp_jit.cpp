@@ -275,6 +275,8 @@ static bool compile_source(const std::string& text, const std::string& arch_opt,
 
 // Test hook (no device, no context): does this bytecode become a kernel for `arch` ("gfx950")?  0 on success; the
 // generated source / compiler log is copied to `log`.
+extern "C" int knp_host_thread_count(void) { return knp_host_threads(); }
+
 extern "C" int knp_jit_compile_check(const int32_t* code, int32_t n_instr, const char* arch, char* log, int32_t log_cap) {
     auto say = [&](const std::string& m) {
         if (log && log_cap > 0) { snprintf(log, (size_t)log_cap, "%s", m.c_str()); }

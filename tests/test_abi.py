@@ -70,3 +70,24 @@ def test_host_graph_builder_under_address_sanitizer():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
     assert r.stdout.count("rc=0") == 2, r.stdout
+
+
+def test_host_threads_follow_the_cpu_share_of_the_process():
+    """The library's one-off host passes (graph build, hierarchy hand-over) are OpenMP loops sized to what the process may use: a GPU box
+    shows every logical CPU of its host (256) inside a 16-core cgroup quota, and 256 threads there made the hand-over 10x slower.
+    ``knp_host_thread_count``: KNP_HOST_THREADS overrides; otherwise at most 32, at most the CPUs of the affinity mask / cgroup quota,
+    divided among the ranks of a node (LOCAL_WORLD_SIZE)."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); from cgx_hip import _lib; print(_lib.load().knp_host_thread_count())"
+            % os.path.join(ROOT, "knp-emi-cgx_amd"))
+
+    def count(**env):
+        e = {k: v for k, v in os.environ.items() if k not in ("KNP_HOST_THREADS", "LOCAL_WORLD_SIZE")}
+        e.update(env)
+        return int(subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, check=True).stdout.split()[-1])
+    base = count()
+    assert 1 <= base <= min(32, len(os.sched_getaffinity(0)))
+    assert count(KNP_HOST_THREADS="3") == 3
+    assert 1 <= count(LOCAL_WORLD_SIZE="2") <= base and count(LOCAL_WORLD_SIZE="4096") == 1
+
